@@ -1,0 +1,288 @@
+/*
+ * dcd_hip.h — C ABI of the MI355X-native DCD rollout-and-regret engine.
+ *
+ * The reference (linjiw/dcd-isaac, pure Python) has no FFI seam for this path:
+ * its boundary is the Python vec-env / storage / sampler API.  This header is
+ * the C-ABI replacement that sits *under* that Python API: each
+ * entry point names the reference function(s) it replaces (file:line into the
+ * reference tree).  The ctypes stub that binds it is dcd-isaac_amd/dcd_hip/
+ * __init__.py; INTEGRATION.md shows the reference-side call sites.
+ *
+ * Conventions
+ *  - every data pointer is a caller-owned DEVICE pointer (hipMalloc / a
+ *    PyTorch-ROCm tensor's data_ptr()); the library never frees or retains it
+ *    beyond the call.  NULL output pointers mean "do not emit".
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream()
+ *    .cuda_stream); every call is asynchronous on it.  No call synchronises
+ *    except dcd_mg_poll_errors().
+ *  - return value: 0 = ok, non-zero = error; dcd_last_error() returns a
+ *    thread-local message.  Device-side semantic errors (bad teacher action,
+ *    missing start position, malformed encoding: the reference's ValueError /
+ *    KeyError / AssertionError sites) are latched per env in an error word that
+ *    dcd_mg_poll_errors() reads back.
+ *  - handles are not thread-safe: one caller thread per handle (the reference's
+ *    learner is single-threaded, train.py:39).
+ *  - integer outputs are bit-exact against oracle/ (the CPU restatement);
+ *    fp32 scans follow the reference's evaluation order with FMA contraction
+ *    off (see each function).
+ */
+#ifndef DCD_HIP_H
+#define DCD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCD_ABI_VERSION 1
+
+/* ---- cell encoding constants (gym-minigrid 1.0.1 OBJECT_TO_IDX etc.; SURVEY
+ * Appendix A.2; used by envs/multigrid/multigrid.py:58,76-101) ------------- */
+enum {
+  DCD_OBJ_UNSEEN = 0, DCD_OBJ_EMPTY = 1, DCD_OBJ_WALL = 2, DCD_OBJ_FLOOR = 3,
+  DCD_OBJ_DOOR = 4, DCD_OBJ_KEY = 5, DCD_OBJ_BALL = 6, DCD_OBJ_BOX = 7,
+  DCD_OBJ_GOAL = 8, DCD_OBJ_LAVA = 9, DCD_OBJ_AGENT = 10
+};
+enum { DCD_ACT_LEFT = 0, DCD_ACT_RIGHT = 1, DCD_ACT_FORWARD = 2, DCD_ACT_PICKUP = 3,
+       DCD_ACT_DROP = 4, DCD_ACT_TOGGLE = 5, DCD_ACT_DONE = 6 };
+
+#define DCD_MAX_GRID 15   /* registered adversarial ids use size 6, 10, 15 */
+#define DCD_MAX_VIEW 7
+
+/* per-env error bits latched on device (dcd_mg_poll_errors) */
+enum {
+  DCD_ERR_BAD_ACTION      = 1u << 0, /* multigrid.py:939 assert False 'unknown action' */
+  DCD_ERR_BAD_ADV_ACTION  = 1u << 1, /* adversarial.py:465-466 ValueError */
+  DCD_ERR_NO_START_POS    = 1u << 2, /* adversarial.py:248-249 ValueError */
+  DCD_ERR_BAD_ENCODING    = 1u << 3, /* multigrid.py:73-105 KeyError / assert */
+  DCD_ERR_NO_FREE_CELL    = 1u << 4, /* multigrid.py:597-599 RetriesExceeded / np.random.choice on empty */
+  DCD_ERR_OUT_OF_GRID     = 1u << 5, /* gym_minigrid Grid.get assert (agent left the grid) */
+  DCD_ERR_BAD_START_CELL  = 1u << 6  /* adversarial.py:259-261 ValueError */
+};
+
+/* flags for dcd_mg_step */
+enum {
+  DCD_STEP_RESET_RANDOM = 1 << 0, /* worker 'step_env_reset_random' (parallel_wrappers.py:31-33) */
+  DCD_STEP_LAST         = 1 << 1  /* runner's last rollout step: force done, mark cliffhangers
+                                      (adversarial_runner.py:521-530) */
+};
+
+/* bits of StepOut.info */
+enum {
+  DCD_INFO_EPISODE     = 1 << 0, /* info['episode'] present (vec_monitor.py:68-83) */
+  DCD_INFO_TRUNC_KEY   = 1 << 1, /* 'truncated' key present (time_limit.py:28-31, runner :526) */
+  DCD_INFO_TRUNCATED   = 1 << 2, /* info['truncated'] value */
+  DCD_INFO_CLIFFHANGER = 1 << 3  /* info['cliffhanger'] (adversarial_runner.py:525) */
+};
+
+/* AdversarialEnv.__init__ (envs/multigrid/adversarial.py:67-149) + TimeLimit
+ * (envs/wrappers/time_limit.py:15-22) + create_parallel_env seeds
+ * (util/__init__.py:213-217). */
+typedef struct DcdMgConfig {
+  int32_t  num_envs;            /* B on this device */
+  int32_t  size;                /* grid width == height, 3..15 */
+  int32_t  agent_view_size;     /* V, odd, 3..7 (all registered ids: 5) */
+  int32_t  max_steps;           /* MultiGridEnv.max_steps (multigrid.py:448,972) */
+  int32_t  max_episode_steps;   /* TimeLimit; <=0: no wrapper */
+  int32_t  n_clutter;
+  int32_t  resample_n_clutter;
+  int32_t  choose_goal_last;
+  int32_t  see_through_walls;   /* must be 1 this round (opaque ids: unsupported) */
+  int32_t  random_z_dim;        /* <= 64 */
+  int32_t  editor_actions;      /* 0 walls_none, 1 walls_none_goal, 2 walls_none_agent_goal */
+  int32_t  fixed_environment;
+  float    goal_noise;
+  uint32_t engine_seed;         /* Philox key word 1 (args.seed) */
+  int64_t  env_index_base;      /* global index of local env 0 (rank * B): default per-env seed */
+} DcdMgConfig;
+
+typedef struct DcdMg DcdMg;     /* opaque: one per (device, env batch) */
+
+/* Student observation of the whole batch (or of n selected envs, row r of each
+ * output = r-th selected env).  gen_obs (multigrid.py:1017-1055) followed by
+ * VecPreprocessImageWrapper._preprocess (obs_wrappers.py:88-115). */
+typedef struct DcdStudentObs {
+  uint8_t* image_u8;   /* [n,V,V,3]  raw encoding, indexed [vx][vy][c]        */
+  uint8_t* dir_u8;     /* [n]                                                 */
+  float*   image_f32;  /* [n,3,V,V]  = u8/10.0 (fp32 division), CHW           */
+  float*   dir_f32;    /* [n,1]                                               */
+} DcdStudentObs;
+
+/* Teacher observation (adversarial.py:222-229,532-537 + obs_wrappers.py:183). */
+typedef struct DcdAdvObs {
+  uint8_t* image_u8;    /* [B,S,S,3] full-grid encoding [x][y][c]             */
+  float*   image_f32;   /* [B,3,S,S] = u8/10.0, CHW                           */
+  float*   time_step;   /* [B,1]                                              */
+  float*   random_z;    /* [B,random_z_dim] U[0,1)                            */
+} DcdAdvObs;
+
+/* Everything worker.step_env + TimeLimit + VecMonitor + VecPreprocess return
+ * for one step, plus the masks the runner derives (adversarial_runner.py:566-573). */
+typedef struct DcdStepOut {
+  DcdStudentObs obs;        /* post-auto-reset obs (parallel_wrappers.py:27-37)         */
+  float*   reward;          /* [B]   fp32(fp64 reward)  (obs_wrappers.py:179)           */
+  uint8_t* done;            /* [B]                                                      */
+  uint8_t* info;            /* [B]   DCD_INFO_* bits                                    */
+  float*   ep_ret;          /* [B]   info['episode']['r'] where DCD_INFO_EPISODE else 0 */
+  int32_t* ep_len;          /* [B]   info['episode']['l']                               */
+  DcdStudentObs term_obs;   /* info['truncated_obs'], rows written ONLY where the
+                               runner would insert it (episode && truncated_obs:
+                               adversarial_runner.py:546-549); other rows untouched   */
+  float*   masks;           /* [B]   0 if done else 1                                   */
+  float*   bad_masks;       /* [B]   0 if 'truncated' key present else 1                */
+  float*   cliffhanger_masks;/*[B]   0 if 'cliffhanger' key present else 1              */
+} DcdStepOut;
+
+const char* dcd_last_error(void);
+int  dcd_abi_version(void);
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* envs.registration.make(id) × B  +  ParallelAdversarialVecEnv.__init__
+ * (envs/registration.py:109-125, envs/wrappers/parallel_wrappers.py:103-145).
+ * `device` is the HIP device ordinal.  Allocates B × 256-byte env records. */
+int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out);
+int dcd_mg_destroy(DcdMg* h);
+/* venv.set_seed(seeds) → MultiGridEnv.seed (parallel_wrappers.py:414-415,
+ * multigrid.py:465-468).  seeds: device int64[B]; resets each env's draw counter. */
+int dcd_mg_set_seed(DcdMg* h, const int64_t* seeds, void* stream);
+/* Reads back (synchronises `stream`) the OR of all per-env error words and the
+ * index of the first offending env; clears them.  first_env may be NULL. */
+int dcd_mg_poll_errors(DcdMg* h, uint32_t* err_bits, int32_t* first_env, void* stream);
+
+/* ---- teacher / level construction ---------------------------------------- */
+/* AdversarialEnv.reset (adversarial.py:194-229) via venv.reset() */
+int dcd_mg_reset(DcdMg* h, const DcdAdvObs* out, void* stream);
+/* AdversarialEnv.step_adversary (adversarial.py:452-539); loc: int64[B];
+ * done: uint8[B] (may be NULL). */
+int dcd_mg_step_adversary(DcdMg* h, const int64_t* loc, const DcdAdvObs* out,
+                          uint8_t* done, void* stream);
+/* AdversarialEnv.reset_agent (adversarial.py:238-269) + TimeLimit/VecMonitor
+ * resets (time_limit.py:47-49, vec_monitor.py:42-46) for the whole batch. */
+int dcd_mg_reset_agent(DcdMg* h, const DcdStudentObs* out, void* stream);
+/* AdversarialEnv.reset_random (adversarial.py:541-581) for the whole batch. */
+int dcd_mg_reset_random(DcdMg* h, const DcdStudentObs* out, void* stream);
+/* reset_to_level with a byte encoding (adversarial.py:271-294, multigrid.py:264-280).
+ * enc: uint8[n,S,S,3]; idx: int32[n] env indices or NULL (n == B, identity). */
+int dcd_mg_reset_to_encoding(DcdMg* h, const uint8_t* enc, const int32_t* idx, int32_t n,
+                             const DcdStudentObs* out, void* stream);
+/* reset_to_level with an action string (adversarial.py:271-288): actions
+ * int64[n,max_len] (row-major), lens int32[n]; replays reset() + step_adversary
+ * per action (+ reset_agent when the design episode ends) in ONE launch. */
+int dcd_mg_reset_to_actions(DcdMg* h, const int64_t* actions, const int32_t* lens,
+                            int32_t max_len, const int32_t* idx, int32_t n,
+                            const DcdStudentObs* out, void* stream);
+/* AdversarialEnv.mutate_level (adversarial.py:317-397), whole batch. */
+int dcd_mg_mutate_level(DcdMg* h, int32_t num_edits, const DcdStudentObs* out, void* stream);
+
+/* ---- the student step ----------------------------------------------------- */
+/* worker.step_env (parallel_wrappers.py:27-37) ∘ TimeLimit.step (time_limit.py:24-33)
+ * ∘ MultiGridEnv.step / step_one_agent / gen_obs (multigrid.py:943-975,866-941,
+ * 1017-1055) ∘ VecMonitor.step_wait (vec_monitor.py:60-85) ∘ VecPreprocessImageWrapper
+ * .step_wait (obs_wrappers.py:168-181) [∘ last-step rule adversarial_runner.py:521-530
+ * when DCD_STEP_LAST].  actions: int64[B]. */
+int dcd_mg_step(DcdMg* h, const int64_t* actions, int32_t flags, const DcdStepOut* out,
+                void* stream);
+
+/* ---- state readback -------------------------------------------------------- */
+/* venv.get_encodings (parallel_wrappers.py:420-421 → adversarial.py:162-164):
+ * uint8[B,S,S,3]. */
+int dcd_mg_get_encodings(DcdMg* h, uint8_t* out, void* stream);
+/* get_num_blocks / get_passable / get_shortest_path_length / get_distance_to_goal
+ * (parallel_wrappers.py:424-431,445-446; adversarial.py:184-192,407-447).
+ * each int32[B]; passable is -1 (unset) / 0 / 1. */
+int dcd_mg_get_metrics(DcdMg* h, int32_t* n_clutter_placed, int32_t* passable,
+                       int32_t* shortest_path_length, int32_t* distance_to_goal, void* stream);
+/* Test/diagnostic readback, int32[B,16]:
+ *  0 agent_x (-1 none) 1 agent_y 2 agent_dir 3 carrying (type|color<<8|state<<16, 0 none)
+ *  4 step_count 5 elapsed_steps 6 ep_len 7 ep_ret (fp32 bits) 8 start_x (-1 none)
+ *  9 start_y 10 start_dir 11 goal_x (-1 none) 12 goal_y 13 adversary_step_count
+ *  14 adversary_max_steps 15 rng draw counter */
+int dcd_mg_get_state(DcdMg* h, int32_t* out, void* stream);
+
+/* ---- RolloutStorage scans (algos/storage.py) ------------------------------- */
+/* compute_gae_returns (storage.py:233-256).  rewards [T,B], value_preds [T+1,B]
+ * (row T already holds next_value; pass truncated_value_preds when
+ * use_proper_time_limits), masks [T+1,B], returns [T+1,B] (rows 0..T-1 written).
+ * Evaluation order per element, every op rounded to fp32, no FMA:
+ *   delta = (r + ((gamma*v[t+1])*m[t+1])) - v[t];
+ *   gae   = delta + (((float)(gamma*lambda) * m[t+1]) * gae);   ret = gae + v[t]. */
+int dcd_gae_returns(const float* rewards, const float* value_preds, const float* masks,
+                    float* returns, int32_t T, int32_t B, double gamma, double gae_lambda,
+                    void* stream);
+/* compute_discounted_returns (storage.py:258-276): ret[T] = v[T];
+ * ret[t] = ((ret[t+1]*gamma)*m[t+1]) + r[t]. */
+int dcd_discounted_returns(const float* rewards, const float* value_preds, const float* masks,
+                           float* returns, int32_t T, int32_t B, double gamma, void* stream);
+/* get_batched_value_loss (storage.py:290-327): out[B] = clamp(mean_t f(R-V)^power, -1, 1).
+ * mode 0 abs, 1 signed, 2 positive-only. */
+int dcd_batched_value_loss(const float* returns, const float* value_preds, float* out,
+                           int32_t T, int32_t B, int32_t mode, int32_t power, int32_t clipped,
+                           void* stream);
+
+/* ---- LevelSampler episode scoring (level_replay/level_sampler.py:486-578) ---- */
+enum {
+  DCD_SCORE_VALUE_L1 = 0,            /* :318-327 */
+  DCD_SCORE_POSITIVE_VALUE_LOSS = 1, /* :340-349 */
+  DCD_SCORE_SIGNED_VALUE_LOSS = 2,   /* :329-338  (== gae :307-316) */
+  DCD_SCORE_POLICY_ENTROPY = 3,      /* :278-287 (with its broadcasting quirk, A.3-10) */
+  DCD_SCORE_LEAST_CONFIDENCE = 4,    /* :289-296 */
+  DCD_SCORE_MIN_MARGIN = 5,          /* :298-305 */
+  DCD_SCORE_ONE_STEP_TD = 6,         /* :426-439 */
+  DCD_SCORE_UNIFORM = 7,             /* :275-276 */
+  DCD_SCORE_RETURN_SUM = 8           /* rewards[start:t].sum() only (grounded_* strategies :533) */
+};
+/* One record per (env, episode segment), emitted in the reference's iteration
+ * order (actor-major, then time): level_sampler.py:497-578. */
+typedef struct DcdEpisodeRec {
+  int32_t actor;        /* env index on this device                         */
+  int32_t seed;         /* level_seeds[start_t, actor]       (:507)          */
+  int32_t start_t;      /* first step of the segment                        */
+  int32_t num_steps;    /* len(episode_logits)               (:541,:572)     */
+  float   mean_score;   /* score_function(...)[0]                            */
+  float   max_score;    /* score_function(...)[1]                            */
+  float   reward_sum;   /* rewards[start:t].sum()  (grounded value, :533)    */
+  int32_t flags;        /* bit0 done (full episode) / 0 trailing partial;
+                           bit1 cliffhanger[t] (score update skipped, :528)  */
+} DcdEpisodeRec;
+/* Segments every env's [0,T) at masks[t]==0 (t>=1), scores each segment.
+ * returns/value_preds [T+1,B]; rewards [T,B]; masks, cliffhanger_masks [T+1,B];
+ * level_seeds int32 [T,B]; action_log_dist [T,B,A] (may be NULL for value
+ * strategies).  recs: capacity max_recs; n_recs: int32[1] total written;
+ * workspace: int32[2*B + 64] scratch.  Order of recs == reference order. */
+int dcd_episode_scores(const float* returns, const float* value_preds, const float* rewards,
+                       const float* masks, const float* cliffhanger_masks,
+                       const int32_t* level_seeds, const float* action_log_dist,
+                       int32_t T, int32_t B, int32_t A, int32_t strategy, double gamma,
+                       DcdEpisodeRec* recs, int32_t max_recs, int32_t* n_recs,
+                       int32_t* workspace, void* stream);
+
+/* ---- regret ---------------------------------------------------------------- */
+/* _get_rollout_return_stats (adversarial_runner.py:257-271): per env mean and max
+ * of the episode returns emitted during a rollout.  ep_ret [T,B] (the per-step
+ * StepOut.ep_ret rows), info uint8 [T,B] (DCD_INFO_EPISODE marks valid entries).
+ * mean is float(np.mean(float32 list)) → computed in fp32 pairwise-free
+ * sequential fp64 accumulate, rounded to fp32 (tolerance 1 ulp documented). */
+int dcd_rollout_return_stats(const float* ep_ret, const uint8_t* info, int32_t T, int32_t B,
+                             float* mean_return, float* max_return, int32_t* n_episodes,
+                             void* stream);
+/* _compute_env_return (adversarial_runner.py:637-674), mode 0 paired
+ * max(antag_max - protag_mean, 0); 1 flexible_paired; 2 minimax (-protag_max). */
+int dcd_env_return(const float* agent_mean, const float* agent_max, const float* adv_mean,
+                   const float* adv_max, float* out, int32_t B, int32_t mode, void* stream);
+
+/* ---- synthetic workload helpers (bench / tests only) ------------- */
+/* actions[i] = mulhi(philox(key=(seed, env_index_base+i), ctr=(t,0,0,0))[0], num_actions) */
+int dcd_random_actions(int64_t* actions, int32_t B, int64_t env_index_base, uint32_t seed,
+                       uint32_t t, int32_t num_actions, void* stream);
+/* K fused random-action student steps in one launch (grid stays in LDS): the
+ * random-agent rollout of models/multigrid_models.py:149-157 without a host round
+ * trip.  Outputs of the LAST step only (any may be NULL); counters accumulate
+ * total episodes/reward into stats int64[2] {episodes, sum of fp32 reward bits unused}. */
+int dcd_mg_step_random(DcdMg* h, uint32_t action_seed, uint32_t t0, int32_t K, int32_t flags,
+                       const DcdStepOut* out, int64_t* n_episodes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCD_HIP_H */

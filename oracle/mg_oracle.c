@@ -1,0 +1,834 @@
+/*
+ * oracle/mg_oracle.c — CPU restatement of the reference's MultiGrid path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under dcd-isaac_amd/ may import, link or
+ * call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / timed CPU baseline.
+ *
+ * What it restates (file:line into the reference tree, which is pure Python):
+ *   envs/multigrid/multigrid.py     Grid.slice :320, rotate_left :300, set_encoding :264,
+ *                                   place_obj :565, place_agent_at_pos :668, get_view_exts :749,
+ *                                   agent_is_done :821, move_agent :840, step_one_agent :866,
+ *                                   step :943, gen_obs_grid :977, gen_agent_obs :1041
+ *   envs/multigrid/adversarial.py   reset :194, reset_agent :238, reset_to_level :271,
+ *                                   reset_to_encoding :290, mutate_level :317, remove_wall :399,
+ *                                   _count_walls :407, compute_shortest_path :423,
+ *                                   step_adversary :452, reset_random :541
+ *   envs/wrappers/time_limit.py     TimeLimit.step :24-33 and its reset_* :35-49
+ *   envs/wrappers/parallel_wrappers.py  worker step_env :27-37
+ *   envs/wrappers/vec_monitor.py    step_wait :60-85, reset_agent :42-46
+ *   envs/wrappers/obs_wrappers.py   _preprocess :88-115 (image/10.0, HWC->CHW, float)
+ *
+ * Third-party semantics (gym-minigrid==1.0.1, gym==0.15.7; requirements.txt:2-3) are
+ * NOT in /root/reference and not installed: OBJECT_TO_IDX / COLOR_TO_IDX / DIR_TO_VEC,
+ * WorldObj.encode / can_overlap / can_pickup, Door/Box.toggle, Grid.encode, wall_rect,
+ * MiniGridEnv._reward are restated from their published behaviour.
+ * The reference has no tests, golden vectors or fixtures for envs/, and envs/ cannot
+ * be imported here (needs gym, gym_minigrid, baselines): PARITY UNPINNED for the env
+ * transition itself.  What IS pinned (tests/test_oracle_env.py): the closed-form
+ * view<->world map of multigrid.py:1080-1093 against this file's slice+rotate render,
+ * the reference's inline asserts as properties, the obs scale (k/10.0 in fp64 -> fp32),
+ * teacher action -> cell map adversarial.py:476-477, unreachable path length 170.
+ *
+ * Randomness: the reference mixes gym's np_random, unseeded process-global np.random and
+ * Python random — not reproducible even against itself.  Contract used here
+ * and in the HIP kernels: one counter-based stream per env, Philox4x32-10 (Salmon et al.,
+ * SC'11) keyed by (env seed, engine seed), counter (n,0,0,0), word 0 of the output;
+ * randint(n) = mulhi32(u, n); uniform = (u >> 8) * 2^-24.  Uniform placement over free
+ * cells (the law of the reference's rejection sampling, multigrid.py:594-624) is drawn as
+ * "k-th free cell in row-major order", one draw per placement.
+ *
+ * Style: deliberately scalar and object-per-cell (struct Obj per cell, one env at a time,
+ * slice + repeated rotate_left for the view) — the opposite of the HIP kernels' packed
+ * bytes / closed-form gather — so that agreement between the two is evidence.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "../include/dcd_hip.h"
+
+/* ------------------------------------------------------------------ Philox4x32-10 */
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                          uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* exported for the known-answer test */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+/* ------------------------------------------------------------------ world objects */
+typedef struct { uint8_t present, type, color, state; } Obj;     /* None <=> present == 0 */
+static const Obj OBJ_NONE = {0, 0, 0, 0};
+
+static Obj mk(uint8_t type, uint8_t color, uint8_t state) { Obj o = {1, type, color, state}; return o; }
+static Obj mk_wall(void)  { return mk(DCD_OBJ_WALL, 5, 0); }  /* Wall() default colour grey */
+static Obj mk_goal(void)  { return mk(DCD_OBJ_GOAL, 1, 0); }  /* Goal(): green            */
+static Obj mk_agent(int dir) { return mk(DCD_OBJ_AGENT, 0, (uint8_t)dir); } /* Agent(0, dir) multigrid.py:126-140 */
+
+/* WorldObj.can_overlap / can_pickup (gym_minigrid) */
+static int can_overlap(Obj o) {
+  if (!o.present) return 0;
+  if (o.type == DCD_OBJ_GOAL || o.type == DCD_OBJ_FLOOR || o.type == DCD_OBJ_LAVA) return 1;
+  if (o.type == DCD_OBJ_DOOR) return o.state == 0;   /* open door */
+  return 0;
+}
+static int can_pickup(Obj o) {
+  return o.present && (o.type == DCD_OBJ_KEY || o.type == DCD_OBJ_BALL || o.type == DCD_OBJ_BOX);
+}
+/* WorldObj.encode / Agent.encode (multigrid.py:138-140); None -> (1,0,0) in Grid.encode */
+static void encode_obj(Obj o, uint8_t out[3]) {
+  if (!o.present) { out[0] = DCD_OBJ_EMPTY; out[1] = 0; out[2] = 0; return; }
+  out[0] = o.type; out[1] = o.color;
+  out[2] = (o.type == DCD_OBJ_DOOR || o.type == DCD_OBJ_AGENT) ? o.state : 0;
+}
+/* WorldObj.decode (multigrid.py:72-107). returns 0 ok, -1 invalid bytes (KeyError/assert). */
+static int decode_obj(uint8_t t, uint8_t c, uint8_t s, Obj* out) {
+  *out = OBJ_NONE;
+  if (t > DCD_OBJ_AGENT) return -1;                       /* IDX_TO_OBJECT KeyError */
+  if (t != DCD_OBJ_AGENT && c > 5) return -1;             /* IDX_TO_COLOR KeyError  */
+  switch (t) {
+    case DCD_OBJ_UNSEEN: case DCD_OBJ_EMPTY: return 0;    /* -> None */
+    case DCD_OBJ_WALL: case DCD_OBJ_FLOOR: case DCD_OBJ_BALL: case DCD_OBJ_KEY: case DCD_OBJ_BOX:
+      *out = mk(t, c, 0); return 0;
+    case DCD_OBJ_DOOR: {                                   /* is_open = s==0, is_locked = s==2 */
+      uint8_t st = (s == 0) ? 0 : (s == 2 ? 2 : 1);
+      *out = mk(t, c, st); return 0; }
+    case DCD_OBJ_GOAL: *out = mk_goal(); return 0;        /* Goal(): colour ignored */
+    case DCD_OBJ_LAVA: *out = mk(DCD_OBJ_LAVA, 0, 0); return 0;
+    case DCD_OBJ_AGENT: *out = mk(DCD_OBJ_AGENT, 0, s); return 0; /* Agent(color_idx,state); id forced 0 :271 */
+  }
+  return -1;
+}
+
+/* ------------------------------------------------------------------ one environment */
+#define MAXG DCD_MAX_GRID
+#define MAXV DCD_MAX_VIEW
+#define MAXZ 64
+
+typedef struct {
+  /* MultiGridEnv (multigrid.py:341-463) */
+  int W, H, V, max_steps;
+  Obj grid[MAXG * MAXG];            /* cell (i,j) at j*W+i (Appendix A.1) */
+  int has_pos, ax, ay, adir;        /* agent_pos[0] / agent_dir[0] */
+  int done;
+  Obj carrying;
+  int step_count;
+  /* AdversarialEnv (adversarial.py:67-149) */
+  int has_start, sx, sy, sdir;      /* agent_start_pos / agent_start_dir */
+  int has_goal, gx, gy;
+  int n_clutter, resample_n_clutter, n_clutter_sampled, adversary_max_steps, adversary_step_count;
+  int choose_goal_last, random_z_dim, n_editor_actions, fixed_environment;
+  float goal_noise;
+  int distance_to_goal, n_clutter_placed, passable, shortest_path_length;
+  /* TimeLimit (time_limit.py) */
+  int elapsed, max_episode_steps;
+  /* VecMonitor (vec_monitor.py:37-46) */
+  float epret; int eplen;
+  /* rng */
+  uint32_t seed, engine_seed, ctr;
+  uint32_t err;
+} Env;
+
+static uint32_t env_rand_u32(Env* e) {
+  uint32_t o[4];
+  philox4x32_10(e->ctr, 0, 0, 0, e->seed, e->engine_seed, o);
+  e->ctr += 1;
+  return o[0];
+}
+static int env_randint(Env* e, int n) {           /* [0, n) */
+  uint32_t u = env_rand_u32(e);
+  return (int)(((uint64_t)u * (uint32_t)n) >> 32);
+}
+static float env_uniform(Env* e) { return (float)(env_rand_u32(e) >> 8) * (1.0f / 16777216.0f); }
+
+static Obj  grid_get(const Env* e, int i, int j) { return e->grid[j * e->W + i]; }
+static void grid_set(Env* e, int i, int j, Obj o) { e->grid[j * e->W + i] = o; }
+static int  in_grid(const Env* e, int i, int j) { return i >= 0 && i < e->W && j >= 0 && j < e->H; }
+
+/* generate_random_z (adversarial.py:449-450): 13 counters, 4 words each, first random_z_dim used */
+static void generate_random_z(Env* e, float* z) {
+  for (int q = 0; q < 13; ++q) {
+    uint32_t o[4];
+    philox4x32_10(e->ctr, 0, 0, 0, e->seed, e->engine_seed, o);
+    e->ctr += 1;
+    for (int w = 0; w < 4; ++w) {
+      int k = q * 4 + w;
+      if (z && k < e->random_z_dim) z[k] = (float)(o[w] >> 8) * (1.0f / 16777216.0f);
+    }
+  }
+}
+
+/* _gen_grid (adversarial.py:166-172): empty grid + wall_rect border */
+static void gen_grid(Env* e) {
+  for (int k = 0; k < e->W * e->H; ++k) e->grid[k] = OBJ_NONE;
+  for (int i = 0; i < e->W; ++i) { grid_set(e, i, 0, mk_wall()); grid_set(e, i, e->H - 1, mk_wall()); }
+  for (int j = 0; j < e->H; ++j) { grid_set(e, 0, j, mk_wall()); grid_set(e, e->W - 1, j, mk_wall()); }
+}
+
+static void reset_metrics(Env* e) {               /* adversarial.py:184-188 */
+  e->distance_to_goal = -1; e->n_clutter_placed = 0; e->passable = -1;
+  e->shortest_path_length = (e->W - 2) * (e->H - 2) + 1;
+}
+
+/* place_obj (multigrid.py:565-632) with top=None,size=None: uniform over cells that are
+ * None and != agent_pos, realised as the k-th such cell in row-major (j, then i) order.
+ * excl_agent: the `np.array_equal(pos, self.agent_pos[a])` rejection (:613-618). */
+static int place_uniform(Env* e, Obj o, int* px, int* py) {
+  int n = 0;
+  for (int j = 0; j < e->H; ++j) for (int i = 0; i < e->W; ++i) {
+    if (grid_get(e, i, j).present) continue;
+    if (e->has_pos && i == e->ax && j == e->ay) continue;
+    ++n;
+  }
+  if (n == 0) { e->err |= DCD_ERR_NO_FREE_CELL; return -1; }
+  int k = env_randint(e, n);
+  for (int j = 0; j < e->H; ++j) for (int i = 0; i < e->W; ++i) {
+    if (grid_get(e, i, j).present) continue;
+    if (e->has_pos && i == e->ax && j == e->ay) continue;
+    if (k-- == 0) { if (o.present) grid_set(e, i, j, o); *px = i; *py = j; return 0; }
+  }
+  return -1;
+}
+
+/* place_agent_at_pos (multigrid.py:668-681): rand_dir=True sets dir = 0 (:670-672) */
+static void place_agent_at_pos(Env* e, int x, int y, int rand_dir) {
+  e->has_pos = 1; e->ax = x; e->ay = y;
+  if (rand_dir) e->adir = 0;
+  grid_set(e, x, y, mk_agent(e->adir));
+}
+/* place_one_agent (multigrid.py:651-666) with top=None */
+static int place_one_agent(Env* e, int rand_dir, int* px, int* py) {
+  e->has_pos = 0;
+  if (place_uniform(e, OBJ_NONE, px, py) != 0) return -1;
+  place_agent_at_pos(e, *px, *py, rand_dir);
+  return 0;
+}
+
+static void reset_agent_status(Env* e) {          /* adversarial.py:231-236 */
+  e->has_pos = 0; e->adir = e->sdir; e->done = 0; e->carrying = OBJ_NONE;
+}
+
+/* ---- observation: gen_obs_grid (multigrid.py:977-1015) literally: slice, rotate, patch */
+static void view_slice(const Env* e, int top_x, int top_y, Obj* out /* V*V, (i,j) at j*V+i */) {
+  int V = e->V;
+  for (int j = 0; j < V; ++j) for (int i = 0; i < V; ++i) {
+    int x = top_x + i, y = top_y + j;
+    out[j * V + i] = in_grid(e, x, y) ? grid_get(e, x, y) : mk_wall();   /* :330-334 */
+  }
+}
+static void view_rotate_left(const Obj* in, Obj* out, int V) {           /* :300-318 */
+  for (int i = 0; i < V; ++i) for (int j = 0; j < V; ++j) {
+    Obj v = in[j * V + i];
+    if (v.present && v.type == DCD_OBJ_AGENT) v.state = (uint8_t)((v.state + 3) & 3);  /* dir -= 1 */
+    out[(V - 1 - i) * V + j] = v;            /* grid.set(j, grid.height-1-i, v) */
+  }
+}
+static void gen_obs(const Env* e, uint8_t* image /* [V][V][3] indexed [vx][vy][c] */, uint8_t* dir) {
+  int V = e->V, top_x, top_y;
+  switch (e->adir) {                                                      /* get_view_exts :749-782 */
+    case 0: top_x = e->ax;             top_y = e->ay - V / 2; break;
+    case 1: top_x = e->ax - V / 2;     top_y = e->ay;         break;
+    case 2: top_x = e->ax - V + 1;     top_y = e->ay - V / 2; break;
+    default: top_x = e->ax - V / 2;    top_y = e->ay - V + 1; break;
+  }
+  Obj a[MAXV * MAXV], b[MAXV * MAXV];
+  view_slice(e, top_x, top_y, a);
+  Obj *cur = a, *nxt = b;
+  for (int r = 0; r < e->adir + 1; ++r) { view_rotate_left(cur, nxt, V); Obj* t = cur; cur = nxt; nxt = t; }
+  /* see_through_walls=True: vis_mask all ones (:1003-1004) */
+  cur[(V - 1) * V + V / 2] = e->carrying;                                 /* :1009-1013 */
+  for (int i = 0; i < V; ++i) for (int j = 0; j < V; ++j)                 /* Grid.encode: [i][j] */
+    encode_obj(cur[j * V + i], image + (i * V + j) * 3);
+  *dir = (uint8_t)e->adir;
+}
+
+/* ---- metrics (adversarial.py:190-192,407-447) */
+static void compute_metrics(Env* e) {
+  int IW = e->W - 2, IH = e->H - 2, n = 0;
+  for (int y = 0; y < IH; ++y) for (int x = 0; x < IW; ++x) {
+    Obj o = grid_get(e, x + 1, y + 1);
+    if (o.present && o.type == DCD_OBJ_WALL) ++n;                         /* isinstance(x, Wall) */
+  }
+  e->n_clutter_placed = n;
+  if (!e->has_start || !e->has_goal) return;                              /* :424-425 */
+  e->distance_to_goal = abs(e->gx - e->sx) + abs(e->gy - e->sy);
+  /* BFS over the interior 4-connected graph with wall nodes removed (:434-447).
+   * NB: only Wall cells are removed from the graph — other objects stay passable. */
+  int dist[MAXG * MAXG], queue[MAXG * MAXG], qh = 0, qt = 0;
+  for (int k = 0; k < IW * IH; ++k) dist[k] = -1;
+  int s = (e->sy - 1) * IW + (e->sx - 1), t = (e->gy - 1) * IW + (e->gx - 1);
+  /* a wall cell under start/goal would be a removed node -> NodeNotFound in networkx;
+   * cannot happen: start/goal cells hold Agent/Goal objects. */
+  dist[s] = 0; queue[qt++] = s;
+  while (qh < qt) {
+    int c = queue[qh++], cx = c % IW, cy = c / IW;
+    static const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};
+    for (int d = 0; d < 4; ++d) {
+      int nx = cx + DX[d], ny = cy + DY[d];
+      if (nx < 0 || nx >= IW || ny < 0 || ny >= IH) continue;
+      Obj o = grid_get(e, nx + 1, ny + 1);
+      if (o.present && o.type == DCD_OBJ_WALL) continue;
+      int k = ny * IW + nx;
+      if (dist[k] >= 0) continue;
+      dist[k] = dist[c] + 1; queue[qt++] = k;
+    }
+  }
+  e->passable = dist[t] >= 0;
+  e->shortest_path_length = e->passable ? dist[t] : IW * IH + 1;
+}
+
+/* ---- AdversarialEnv.reset (adversarial.py:194-229) */
+static void env_reset(Env* e, uint8_t* image, float* time_step, float* z) {
+  e->step_count = 0; e->adversary_step_count = 0;
+  if (e->resample_n_clutter) e->n_clutter_sampled = 0;
+  /* fixed_environment: MultiGridEnv.reset re-seeds (multigrid.py:471-472); AdversarialEnv.reset
+   * overrides it without re-seeding, reset_random does re-seed (:542-543). */
+  e->sdir = env_randint(e, 4);
+  reset_agent_status(e);
+  e->has_start = 0; e->has_goal = 0;
+  e->done = 0;
+  reset_metrics(e);
+  gen_grid(e);
+  if (image) for (int i = 0; i < e->W; ++i) for (int j = 0; j < e->H; ++j)
+    encode_obj(grid_get(e, i, j), image + (i * e->H + j) * 3);
+  if (time_step) *time_step = (float)e->adversary_step_count;
+  generate_random_z(e, z);
+}
+
+/* ---- AdversarialEnv.reset_agent (adversarial.py:238-269).  TimeLimit's _elapsed_steps is
+ * zeroed by the CALLERS that go through the wrapper (time_limit.py:35-49): mutate_level does
+ * not (gym.Wrapper.__getattr__ forwards it past TimeLimit). */
+static void env_reset_agent(Env* e) {
+  if (e->has_pos) grid_set(e, e->ax, e->ay, OBJ_NONE);
+  reset_agent_status(e);
+  e->step_count = 0;
+  if (!e->has_start) { e->err |= DCD_ERR_NO_START_POS; return; }
+  place_agent_at_pos(e, e->sx, e->sy, 0);
+  /* :257-261 check is vacuous after placement (cell holds the Agent) */
+}
+
+static void remove_wall(Env* e, int x, int y) {    /* adversarial.py:399-405 (wall_locs: see DESIGN) */
+  Obj o = grid_get(e, x, y);
+  if (o.present && o.type == DCD_OBJ_WALL) { grid_set(e, x, y, OBJ_NONE); e->n_clutter_placed -= 1; }
+}
+
+/* ---- step_adversary (adversarial.py:452-539). returns done. */
+static int env_step_adversary(Env* e, int64_t loc, uint8_t* image, float* time_step, float* z) {
+  int IW = e->W - 2;
+  int dim = IW * (e->H - 2);
+  if (loc < 0 || loc >= dim) { e->err |= DCD_ERR_BAD_ADV_ACTION; loc = 0; }
+  if (e->resample_n_clutter && !e->n_clutter_sampled) {                   /* :469-472 */
+    int nc = (int)(((double)loc / (double)dim) * (double)e->n_clutter);
+    e->adversary_max_steps = nc + 2;
+    e->n_clutter_sampled = 1;
+  }
+  if (e->adversary_step_count < e->adversary_max_steps) {
+    int x = (int)(loc % IW) + 1, y = (int)(loc / IW) + 1;
+    int choose_goal, choose_agent;
+    if (e->choose_goal_last) {
+      choose_goal = e->adversary_step_count == e->adversary_max_steps - 2;
+      choose_agent = e->adversary_step_count == e->adversary_max_steps - 1;
+    } else {
+      choose_goal = e->adversary_step_count == 0;
+      choose_agent = e->adversary_step_count == 1;
+    }
+    if (choose_goal) {
+      int noisy = 0;
+      if (e->goal_noise > 0.0f) noisy = env_uniform(e) < e->goal_noise;   /* :493 */
+      if (noisy) {
+        int px, py;
+        if (place_uniform(e, mk_goal(), &px, &py) == 0) { e->has_goal = 1; e->gx = px; e->gy = py; }
+      } else {
+        remove_wall(e, x, y);
+        grid_set(e, x, y, mk_goal());                                     /* put_obj overwrites */
+        e->has_goal = 1; e->gx = x; e->gy = y;
+      }
+    } else if (choose_agent) {
+      remove_wall(e, x, y);
+      if (grid_get(e, x, y).present) {                                    /* goal already here :505 */
+        int px, py;
+        if (place_one_agent(e, 0, &px, &py) == 0) { e->has_start = 1; e->sx = px; e->sy = py; }
+      } else {
+        e->has_start = 1; e->sx = x; e->sy = y;
+        place_agent_at_pos(e, x, y, 0);
+      }
+    } else {
+      if (!grid_get(e, x, y).present) {                                   /* :517-520 */
+        grid_set(e, x, y, mk_wall());
+        e->n_clutter_placed += 1;
+      }
+    }
+  }
+  e->adversary_step_count += 1;
+  int done = 0;
+  if (e->adversary_step_count >= e->n_clutter + 2) {                      /* :525 (n_clutter, not max_steps) */
+    done = 1;
+    reset_metrics(e);
+    compute_metrics(e);
+  }
+  if (image) for (int i = 0; i < e->W; ++i) for (int j = 0; j < e->H; ++j)
+    encode_obj(grid_get(e, i, j), image + (i * e->H + j) * 3);
+  if (time_step) *time_step = (float)e->adversary_step_count;
+  generate_random_z(e, z);
+  return done;
+}
+
+/* ---- reset_to_level with encoding (adversarial.py:271-294; multigrid.py:264-280) */
+static void env_reset_to_encoding(Env* e, const uint8_t* enc /* [S][S][3] */) {
+  env_reset(e, NULL, NULL, NULL);
+  e->elapsed = 0;                                                         /* time_limit.py:43-45 */
+  for (int i = 0; i < e->H; ++i) for (int j = 0; j < e->W; ++j) {
+    const uint8_t* c = enc + (i * e->W + j) * 3;
+    Obj v;
+    if (decode_obj(c[0], c[1], c[2], &v) != 0) { e->err |= DCD_ERR_BAD_ENCODING; v = OBJ_NONE; }
+    if (v.present && v.type == DCD_OBJ_AGENT) { e->has_start = 1; e->sx = i; e->sy = j; }
+    else if (v.present && v.type == DCD_OBJ_GOAL) { e->has_goal = 1; e->gx = i; e->gy = j; }
+    grid_set(e, i, j, v);
+  }
+  compute_metrics(e);
+  env_reset_agent(e);
+}
+
+/* ---- reset_random (adversarial.py:541-581) */
+static void env_reset_random(Env* e) {
+  if (e->fixed_environment) e->ctr = 0;                                   /* self.seed(seed_value) */
+  e->step_count = 0; e->adversary_step_count = 0;
+  reset_agent_status(e);
+  e->has_start = 0; e->has_goal = 0;
+  reset_metrics(e);
+  gen_grid(e);
+  int px, py;
+  if (place_uniform(e, mk_goal(), &px, &py) == 0) { e->has_goal = 1; e->gx = px; e->gy = py; }
+  e->sdir = env_randint(e, 4);
+  if (place_one_agent(e, 0, &px, &py) == 0) { e->has_start = 1; e->sx = px; e->sy = py; }
+  int nc;
+  if (e->resample_n_clutter) {                                            /* :151-156 */
+    nc = env_randint(e, e->n_clutter);
+    e->adversary_max_steps = nc + 2; e->n_clutter_sampled = 1;
+  } else nc = e->n_clutter / 2;
+  for (int k = 0; k < nc; ++k) place_uniform(e, mk_wall(), &px, &py);
+  compute_metrics(e);
+  env_reset_agent(e);
+}
+
+/* ---- mutate_level (adversarial.py:317-397) */
+static void env_mutate_level(Env* e, int num_edits) {
+  int IW = e->W - 2, IH = e->H - 2, ntiles = IW * IH;
+  int locs[64], nloc = 0;
+  if (num_edits > 64) num_edits = 64;
+  for (int k = 0; k < num_edits; ++k) {                                   /* set(): dedup, keep first */
+    int l = env_randint(e, ntiles), dup = 0;
+    for (int q = 0; q < nloc; ++q) if (locs[q] == l) dup = 1;
+    if (!dup) locs[nloc++] = l;
+  }
+  int acts[64];
+  for (int k = 0; k < nloc; ++k) acts[k] = env_randint(e, e->n_editor_actions);
+  /* free_mask = ~wall_mask, minus agent start and goal (:332-334) */
+  uint8_t free_mask[MAXG * MAXG];
+  for (int y = 0; y < IH; ++y) for (int x = 0; x < IW; ++x) {
+    Obj o = grid_get(e, x + 1, y + 1);
+    free_mask[y * IW + x] = !(o.present && o.type == DCD_OBJ_WALL);
+  }
+  if (e->has_start) free_mask[(e->sy - 1) * IW + (e->sx - 1)] = 0;
+  if (e->has_goal)  free_mask[(e->gy - 1) * IW + (e->gx - 1)] = 0;
+  for (int k = 0; k < nloc; ++k) {
+    int x = locs[k] % IW + 1, y = locs[k] / IW + 1;
+    /* _clean_loc (:296-306) */
+    remove_wall(e, x, y);
+    Obj o = grid_get(e, x, y);
+    if (o.present && o.type == DCD_OBJ_GOAL) e->has_goal = 0;
+    else if (o.present && o.type == DCD_OBJ_AGENT) e->has_start = 0;
+    grid_set(e, x, y, OBJ_NONE);
+    /* editor_actions values: ['-','.'] / ['-','.','g'] / ['-','.','a','g'] (:40-56) */
+    char a;
+    if (acts[k] == 0) a = '-'; else if (acts[k] == 1) a = '.';
+    else if (e->n_editor_actions == 3) a = 'g';
+    else a = (acts[k] == 2) ? 'a' : 'g';
+    if (a == '-') {
+      grid_set(e, x, y, mk_wall()); e->n_clutter_placed += 1; free_mask[(y - 1) * IW + x - 1] = 0;
+    } else if (a == '.') {
+      free_mask[(y - 1) * IW + x - 1] = 1;
+    } else if (a == 'a') {
+      if (e->has_start) { grid_set(e, e->sx, e->sy, OBJ_NONE); free_mask[(e->sy - 1) * IW + e->sx - 1] = 1; }
+      place_agent_at_pos(e, x, y, 1);               /* place_one_agent(top=(x,y),size=(1,1)): dir := 0 */
+      e->has_start = 1; e->sx = x; e->sy = y;
+      free_mask[(y - 1) * IW + x - 1] = 0;
+    } else {
+      if (e->has_goal) { grid_set(e, e->gx, e->gy, OBJ_NONE); free_mask[(e->gy - 1) * IW + e->gx - 1] = 1; }
+      grid_set(e, x, y, mk_goal());
+      e->has_goal = 1; e->gx = x; e->gy = y;
+      free_mask[(y - 1) * IW + x - 1] = 0;
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {            /* goal first, then agent (:370-388) */
+    if (pass == 0 ? e->has_goal : e->has_start) continue;
+    int n = 0;
+    for (int k = 0; k < ntiles; ++k) n += free_mask[k];
+    if (n == 0) { e->err |= DCD_ERR_NO_FREE_CELL; continue; }
+    int kk = env_randint(e, n), sel = -1;
+    for (int k = 0; k < ntiles; ++k) if (free_mask[k] && kk-- == 0) { sel = k; break; }
+    free_mask[sel] = 0;
+    int x = sel % IW + 1, y = sel / IW + 1;
+    if (pass == 0) { grid_set(e, x, y, mk_goal()); e->has_goal = 1; e->gx = x; e->gy = y; }
+    else { place_agent_at_pos(e, x, y, 1); e->has_start = 1; e->sx = x; e->sy = y; }
+  }
+  e->step_count = 0; e->adversary_step_count = 0;
+  reset_metrics(e);
+  compute_metrics(e);
+  env_reset_agent(e);
+}
+
+/* ---- agent_is_done (multigrid.py:821-838) */
+static void agent_is_done(Env* e) {
+  grid_set(e, e->ax, e->ay, OBJ_NONE);
+  e->done = 1;
+  int px, py;
+  if (e->carrying.present) {                       /* respawn the carried object first */
+    place_uniform(e, e->carrying, &px, &py);       /* agent_pos still set: excluded (:613-618) */
+    e->carrying = OBJ_NONE;
+  }
+  place_one_agent(e, 1, &px, &py);                 /* rand_dir=True -> dir 0 */
+}
+
+/* ---- step_one_agent (multigrid.py:866-941); returns reward as fp64 like Python */
+static double step_one_agent(Env* e, int action) {
+  static const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};         /* DIR_TO_VEC */
+  double reward = 0.0;
+  int fx = e->ax + DX[e->adir], fy = e->ay + DY[e->adir];
+  int fwd_ok = in_grid(e, fx, fy);
+  if (!fwd_ok) e->err |= DCD_ERR_OUT_OF_GRID;      /* Grid.get asserts in the reference */
+  Obj fwd = fwd_ok ? grid_get(e, fx, fy) : mk_wall();
+  switch (action) {
+    case DCD_ACT_LEFT:
+      e->adir -= 1; if (e->adir < 0) e->adir += 4;
+      grid_set(e, e->ax, e->ay, mk_agent(e->adir));                       /* rotate_agent :855 */
+      break;
+    case DCD_ACT_RIGHT:
+      e->adir = (e->adir + 1) % 4;
+      grid_set(e, e->ax, e->ay, mk_agent(e->adir));
+      break;
+    case DCD_ACT_FORWARD:
+      if (!fwd_ok) break;
+      if (fwd.present && fwd.type == DCD_OBJ_GOAL) {
+        agent_is_done(e);
+        reward = 1.0 - 0.9 * ((double)e->step_count / (double)e->max_steps);  /* _reward() */
+      } else if (fwd.present && fwd.type == DCD_OBJ_LAVA) {
+        agent_is_done(e);
+      } else if (!fwd.present || can_overlap(fwd)) {                      /* move_agent :840-853 */
+        grid_set(e, e->ax, e->ay, OBJ_NONE);
+        e->ax = fx; e->ay = fy;
+        grid_set(e, fx, fy, mk_agent(e->adir));
+      }
+      break;
+    case DCD_ACT_PICKUP:
+      if (fwd_ok && can_pickup(fwd) && !e->carrying.present) {
+        e->carrying = fwd; grid_set(e, fx, fy, OBJ_NONE);
+      }
+      break;
+    case DCD_ACT_DROP:
+      if (fwd_ok && !fwd.present && e->carrying.present) {
+        grid_set(e, fx, fy, e->carrying); e->carrying = OBJ_NONE;
+      }
+      break;
+    case DCD_ACT_TOGGLE:
+      if (fwd_ok && fwd.present) {
+        if (fwd.type == DCD_OBJ_DOOR) {                                   /* Door.toggle multigrid.py:113-123 */
+          if (fwd.state == 2) {
+            if (e->carrying.present && e->carrying.type == DCD_OBJ_KEY && e->carrying.color == fwd.color) {
+              fwd.state = 0; grid_set(e, fx, fy, fwd);
+            }
+          } else { fwd.state = fwd.state == 0 ? 1 : 0; grid_set(e, fx, fy, fwd); }
+        } else if (fwd.type == DCD_OBJ_BOX) {
+          grid_set(e, fx, fy, OBJ_NONE);           /* Box.toggle: replaced by contents (None) */
+        }
+      }
+      break;
+    case DCD_ACT_DONE: break;
+    default: e->err |= DCD_ERR_BAD_ACTION; break;
+  }
+  return reward;
+}
+
+/* ------------------------------------------------------------------ batch handle */
+typedef struct OrcMg {
+  DcdMgConfig cfg;
+  Env* envs;
+} OrcMg;
+
+static float div10(uint8_t k) { return (float)((double)k / 10.0); }       /* obs_wrappers.py:90-91 */
+
+static void emit_student_obs(const Env* e, int row, const DcdStudentObs* o) {
+  if (!o) return;
+  int V = e->V;
+  uint8_t img[MAXV * MAXV * 3], dir;
+  if (!e->has_pos) { memset(img, 0, sizeof img); dir = 0; }
+  else gen_obs(e, img, &dir);
+  if (o->image_u8) memcpy(o->image_u8 + (size_t)row * V * V * 3, img, (size_t)V * V * 3);
+  if (o->dir_u8) o->dir_u8[row] = dir;
+  if (o->image_f32) {
+    float* f = o->image_f32 + (size_t)row * 3 * V * V;
+    for (int c = 0; c < 3; ++c) for (int i = 0; i < V; ++i) for (int j = 0; j < V; ++j)
+      f[(c * V + i) * V + j] = div10(img[(i * V + j) * 3 + c]);
+  }
+  if (o->dir_f32) o->dir_f32[row] = (float)dir;
+}
+
+static void emit_adv_obs(const Env* e, int row, const DcdAdvObs* o, const uint8_t* img,
+                         float ts, const float* z) {
+  if (!o) return;
+  int S = e->W;
+  if (o->image_u8) memcpy(o->image_u8 + (size_t)row * S * S * 3, img, (size_t)S * S * 3);
+  if (o->image_f32) {
+    float* f = o->image_f32 + (size_t)row * 3 * S * S;
+    for (int c = 0; c < 3; ++c) for (int i = 0; i < S; ++i) for (int j = 0; j < S; ++j)
+      f[(c * S + i) * S + j] = div10(img[(i * S + j) * 3 + c]);
+  }
+  if (o->time_step) o->time_step[row] = ts;
+  if (o->random_z) memcpy(o->random_z + (size_t)row * e->random_z_dim, z, sizeof(float) * e->random_z_dim);
+}
+
+OrcMg* orc_mg_create(const DcdMgConfig* cfg) {
+  if (!cfg || cfg->size < 3 || cfg->size > MAXG || cfg->agent_view_size > MAXV ||
+      !(cfg->agent_view_size & 1) || cfg->random_z_dim > 52 || !cfg->see_through_walls) return NULL;
+  OrcMg* h = (OrcMg*)calloc(1, sizeof(OrcMg));
+  h->cfg = *cfg;
+  h->envs = (Env*)calloc((size_t)cfg->num_envs, sizeof(Env));
+  static const int NEDIT[3] = {2, 3, 4};
+  for (int b = 0; b < cfg->num_envs; ++b) {
+    Env* e = &h->envs[b];
+    e->W = e->H = cfg->size; e->V = cfg->agent_view_size; e->max_steps = cfg->max_steps;
+    e->n_clutter = cfg->n_clutter; e->resample_n_clutter = cfg->resample_n_clutter;
+    e->adversary_max_steps = cfg->n_clutter + 2;                          /* :107 */
+    e->choose_goal_last = cfg->choose_goal_last; e->random_z_dim = cfg->random_z_dim;
+    e->n_editor_actions = NEDIT[cfg->editor_actions]; e->fixed_environment = cfg->fixed_environment;
+    e->goal_noise = cfg->goal_noise; e->max_episode_steps = cfg->max_episode_steps;
+    e->seed = (uint32_t)(cfg->env_index_base + b); e->engine_seed = cfg->engine_seed; e->ctr = 0;
+    /* MultiGridEnv.__init__ -> reset() (multigrid.py:463): an empty walled grid */
+    env_reset(e, NULL, NULL, NULL);
+  }
+  return h;
+}
+void orc_mg_destroy(OrcMg* h) { if (h) { free(h->envs); free(h); } }
+
+void orc_mg_set_seed(OrcMg* h, const int64_t* seeds) {
+  for (int b = 0; b < h->cfg.num_envs; ++b) { h->envs[b].seed = (uint32_t)seeds[b]; h->envs[b].ctr = 0; }
+}
+uint32_t orc_mg_poll_errors(OrcMg* h, int32_t* first_env) {
+  uint32_t all = 0; int first = -1;
+  for (int b = 0; b < h->cfg.num_envs; ++b) {
+    if (h->envs[b].err && first < 0) first = b;
+    all |= h->envs[b].err; h->envs[b].err = 0;
+  }
+  if (first_env) *first_env = first;
+  return all;
+}
+
+void orc_mg_reset(OrcMg* h, const DcdAdvObs* out) {
+  uint8_t img[MAXG * MAXG * 3]; float ts, z[MAXZ];
+  for (int b = 0; b < h->cfg.num_envs; ++b) {
+    Env* e = &h->envs[b];
+    env_reset(e, img, &ts, z);
+    e->elapsed = 0;                                                       /* time_limit.py:35-37 */
+    e->epret = 0.f; e->eplen = 0;                                         /* vec_monitor.py:36-40 */
+    emit_adv_obs(e, b, out, img, ts, z);
+  }
+}
+void orc_mg_step_adversary(OrcMg* h, const int64_t* loc, const DcdAdvObs* out, uint8_t* done) {
+  uint8_t img[MAXG * MAXG * 3]; float ts, z[MAXZ];
+  for (int b = 0; b < h->cfg.num_envs; ++b) {
+    Env* e = &h->envs[b];
+    int d = env_step_adversary(e, loc[b], img, &ts, z);
+    if (done) done[b] = (uint8_t)d;
+    emit_adv_obs(e, b, out, img, ts, z);
+  }
+}
+void orc_mg_reset_agent(OrcMg* h, const DcdStudentObs* out) {
+  for (int b = 0; b < h->cfg.num_envs; ++b) {
+    Env* e = &h->envs[b];
+    env_reset_agent(e);
+    e->elapsed = 0;                                                       /* time_limit.py:47-49 */
+    e->epret = 0.f; e->eplen = 0;                                         /* vec_monitor.py:42-46 */
+    emit_student_obs(e, b, out);
+  }
+}
+void orc_mg_reset_random(OrcMg* h, const DcdStudentObs* out) {
+  for (int b = 0; b < h->cfg.num_envs; ++b) {
+    Env* e = &h->envs[b];
+    env_reset_random(e);
+    e->elapsed = 0;                                                       /* time_limit.py:39-41 */
+    e->epret = 0.f; e->eplen = 0;                                         /* vec_monitor.py:48-52 */
+    emit_student_obs(e, b, out);
+  }
+}
+void orc_mg_reset_to_encoding(OrcMg* h, const uint8_t* enc, const int32_t* idx, int32_t n,
+                              const DcdStudentObs* out) {
+  int S = h->cfg.size;
+  for (int r = 0; r < n; ++r) {
+    Env* e = &h->envs[idx ? idx[r] : r];
+    env_reset_to_encoding(e, enc + (size_t)r * S * S * 3);
+    emit_student_obs(e, r, out);
+  }
+}
+void orc_mg_reset_to_actions(OrcMg* h, const int64_t* actions, const int32_t* lens, int32_t max_len,
+                             const int32_t* idx, int32_t n, const DcdStudentObs* out) {
+  for (int r = 0; r < n; ++r) {
+    Env* e = &h->envs[idx ? idx[r] : r];
+    env_reset(e, NULL, NULL, NULL);                                       /* adversarial.py:272 */
+    e->elapsed = 0;
+    if (e->resample_n_clutter) e->adversary_max_steps = lens[r];          /* :277-278 */
+    for (int k = 0; k < lens[r]; ++k) {
+      int d = env_step_adversary(e, actions[(size_t)r * max_len + k], NULL, NULL, NULL);
+      if (d) env_reset_agent(e);                                          /* :281-283 */
+    }
+    emit_student_obs(e, r, out);
+  }
+}
+void orc_mg_mutate_level(OrcMg* h, int32_t num_edits, const DcdStudentObs* out) {
+  for (int b = 0; b < h->cfg.num_envs; ++b) {
+    Env* e = &h->envs[b];
+    env_mutate_level(e, num_edits);
+    emit_student_obs(e, b, out);
+  }
+}
+
+/* ---- the student step: worker.step_env ∘ TimeLimit.step ∘ MultiGridEnv.step ∘ VecMonitor */
+static void orc_step_one(OrcMg* h, int b, int64_t action, int32_t flags, const DcdStepOut* out) {
+  Env* e = &h->envs[b];
+  /* MultiGridEnv.step (multigrid.py:943-975) */
+  e->step_count += 1;
+  int act = (action < 0 || action > 6) ? 7 : (int)action;
+  double reward = step_one_agent(e, act);
+  int done = e->done >= 1;                                                /* competitive (n_agents==1) */
+  if (e->step_count >= e->max_steps) done = 1;
+  uint8_t info = 0;
+  int have_term = 0;
+  /* TimeLimit.step (time_limit.py:24-33): obs here is the pre-auto-reset observation */
+  if (e->max_episode_steps > 0) {
+    e->elapsed += 1;
+    if (e->elapsed >= e->max_episode_steps) {
+      info |= DCD_INFO_TRUNC_KEY;
+      if (!done) info |= DCD_INFO_TRUNCATED;
+      have_term = 1;
+      done = 1;
+    }
+  }
+  /* worker step_env auto-reset (parallel_wrappers.py:27-37) happens in the worker, i.e. BEFORE
+   * VecMonitor sees the step; the terminal obs must be rendered before it. */
+  uint8_t term_img[MAXV * MAXV * 3], term_dir = 0;
+  if (have_term) gen_obs(e, term_img, &term_dir);
+  if (done) {
+    if (flags & DCD_STEP_RESET_RANDOM) { env_reset_random(e); }           /* then reset_agent again */
+    env_reset_agent(e);
+    e->elapsed = 0;                                                       /* time_limit.py:39-49 */
+  }
+  /* VecMonitor.step_wait (vec_monitor.py:60-85): eprets(f32) += rews(f64) */
+  e->epret = (float)((double)e->epret + reward);
+  e->eplen += 1;
+  float ep_r = 0.f; int ep_l = 0;
+  if (done) { info |= DCD_INFO_EPISODE; ep_r = e->epret; ep_l = e->eplen; e->epret = 0.f; e->eplen = 0; }
+  /* runner last-step rule (adversarial_runner.py:521-530), use_proper_time_limits assumed */
+  int cliff_obs = 0;
+  if (flags & DCD_STEP_LAST) {
+    if (!done) { info |= DCD_INFO_CLIFFHANGER | DCD_INFO_TRUNC_KEY | DCD_INFO_TRUNCATED; cliff_obs = 1; }
+    done = 1;
+  }
+  (void)cliff_obs;   /* cliffhanger truncated_obs is never inserted: no 'episode' key (:539-549) */
+  if (!out) return;
+  emit_student_obs(e, b, &out->obs);
+  if (out->reward) out->reward[b] = (float)reward;                        /* obs_wrappers.py:179 */
+  if (out->done) out->done[b] = (uint8_t)done;
+  if (out->info) out->info[b] = info;
+  if (out->ep_ret) out->ep_ret[b] = ep_r;
+  if (out->ep_len) out->ep_len[b] = ep_l;
+  if ((info & DCD_INFO_EPISODE) && have_term) {                           /* runner :539-549 */
+    int V = e->V;
+    const DcdStudentObs* t = &out->term_obs;
+    if (t->image_u8) memcpy(t->image_u8 + (size_t)b * V * V * 3, term_img, (size_t)V * V * 3);
+    if (t->dir_u8) t->dir_u8[b] = term_dir;
+    if (t->image_f32) {
+      float* f = t->image_f32 + (size_t)b * 3 * V * V;
+      for (int c = 0; c < 3; ++c) for (int i = 0; i < V; ++i) for (int j = 0; j < V; ++j)
+        f[(c * V + i) * V + j] = div10(term_img[(i * V + j) * 3 + c]);
+    }
+    if (t->dir_f32) t->dir_f32[b] = (float)term_dir;
+  }
+  if (out->masks) out->masks[b] = done ? 0.f : 1.f;                       /* runner :566-573 */
+  if (out->bad_masks) out->bad_masks[b] = (info & DCD_INFO_TRUNC_KEY) ? 0.f : 1.f;
+  if (out->cliffhanger_masks) out->cliffhanger_masks[b] = (info & DCD_INFO_CLIFFHANGER) ? 0.f : 1.f;
+}
+
+void orc_mg_step(OrcMg* h, const int64_t* actions, int32_t flags, const DcdStepOut* out) {
+  for (int b = 0; b < h->cfg.num_envs; ++b) orc_step_one(h, b, actions[b], flags, out);
+}
+
+/* OpenMP-free multi-thread helper for the cpu_baseline leg: steps envs [lo,hi) only. */
+void orc_mg_step_range(OrcMg* h, const int64_t* actions, int32_t flags, const DcdStepOut* out,
+                       int32_t lo, int32_t hi) {
+  for (int b = lo; b < hi; ++b) orc_step_one(h, b, actions[b], flags, out);
+}
+
+void orc_mg_get_encodings(OrcMg* h, uint8_t* out) {
+  int S = h->cfg.size;
+  for (int b = 0; b < h->cfg.num_envs; ++b) {
+    Env* e = &h->envs[b];
+    for (int i = 0; i < S; ++i) for (int j = 0; j < S; ++j)
+      encode_obj(grid_get(e, i, j), out + ((size_t)b * S * S + i * S + j) * 3);
+  }
+}
+void orc_mg_get_metrics(OrcMg* h, int32_t* ncl, int32_t* passable, int32_t* spl, int32_t* dist) {
+  for (int b = 0; b < h->cfg.num_envs; ++b) {
+    Env* e = &h->envs[b];
+    if (ncl) ncl[b] = e->n_clutter_placed;
+    if (passable) passable[b] = e->passable;
+    if (spl) spl[b] = e->shortest_path_length;
+    if (dist) dist[b] = e->distance_to_goal;
+  }
+}
+void orc_mg_get_state(OrcMg* h, int32_t* out) {
+  for (int b = 0; b < h->cfg.num_envs; ++b) {
+    Env* e = &h->envs[b];
+    int32_t* o = out + (size_t)b * 16;
+    uint8_t c[3] = {0, 0, 0};
+    if (e->carrying.present) encode_obj(e->carrying, c);
+    o[0] = e->has_pos ? e->ax : -1; o[1] = e->has_pos ? e->ay : -1; o[2] = e->adir;
+    o[3] = e->carrying.present ? (c[0] | (c[1] << 8) | (c[2] << 16)) : 0;
+    o[4] = e->step_count; o[5] = e->elapsed; o[6] = e->eplen;
+    memcpy(&o[7], &e->epret, 4);
+    o[8] = e->has_start ? e->sx : -1; o[9] = e->has_start ? e->sy : -1; o[10] = e->sdir;
+    o[11] = e->has_goal ? e->gx : -1; o[12] = e->has_goal ? e->gy : -1;
+    o[13] = e->adversary_step_count; o[14] = e->adversary_max_steps; o[15] = (int32_t)e->ctr;
+  }
+}
+
+/* actions[i] = mulhi(philox(key=(seed, base+i), ctr=(t,0,0,0))[0], num_actions) */
+void orc_random_actions(int64_t* actions, int32_t B, int64_t base, uint32_t seed, uint32_t t,
+                        int32_t num_actions) {
+  for (int b = 0; b < B; ++b) {
+    uint32_t o[4];
+    philox4x32_10(t, 0, 0, 0, seed, (uint32_t)(base + b), o);
+    actions[b] = (int64_t)(((uint64_t)o[0] * (uint32_t)num_actions) >> 32);
+  }
+}
+
+/* closed-form view<->world map of compute_agent_visibility_mask (multigrid.py:1080-1093):
+ * world = agent + f*(V-1-vy) + r*(vx - V//2).  Exported so tests can pin gen_obs (the
+ * slice+rotate statement) against the reference's second, independent statement. */
+void orc_view_to_world(int ax, int ay, int dir, int V, int vx, int vy, int* wx, int* wy) {
+  static const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};
+  int fx = DX[dir], fy = DY[dir], rx = -fy, ry = fx;          /* right_vec :697-700 */
+  int tlx = ax + fx * (V - 1) - rx * (V / 2), tly = ay + fy * (V - 1) - ry * (V / 2);
+  *wx = tlx - fx * vy + rx * vx;
+  *wy = tly - fy * vy + ry * vx;
+}
