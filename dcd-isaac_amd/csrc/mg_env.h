@@ -1,0 +1,558 @@
+// mg_env.h — per-environment MultiGrid logic on a packed 256-byte env record.
+//
+// One env = one 256-byte record (2 × 128-B L2 lines), staged into LDS by the kernels in
+// mg_kernels.hip and owned by ONE lane while it is there:
+//
+//   byte y*16 + x   (x,y < 15)  packed cell code of grid cell (x,y)           rows 0..14
+//   byte y*16 + 15  (y < 15)    "side column" SB[y]: per-level scalars
+//        SB0 start_x (0xFF none)  SB1 start_y  SB2 start_dir  SB3 goal_x (0xFF none)  SB4 goal_y
+//        SB5 flags (bit0 n_clutter_sampled)    SB6 adversary_step_count  SB7 adversary_max_steps
+//        SB8..11 rng draw counter (LE u32)     SB12..14 spare
+//   bytes 240..255  dynamic state (the only part the hot step always rewrites)
+//        240 agent_x (0xFF none) 241 agent_y 242 agent_dir 243 carrying (cell code, 0 none)
+//        244 step_count u16   246 elapsed_steps u16 (TimeLimit)   248 ep_len u16 (VecMonitor)
+//        250 env.done  251 spare   252 ep_ret f32 (VecMonitor)
+//
+// Packed cell codes (55 values; decode(encode(code)) is the identity, and set_encoding's
+// normalisations — Goal() colour, door state>=3, agent id — are built in):
+//   0 None | 1+c wall | 7+c floor | 13+c key | 19+c ball | 25+c box | 31 goal | 32 lava |
+//   33+d agent facing d | 37+3c+s door (s: 0 open, 1 closed, 2 locked)         c = colour 0..5
+//
+// Semantics follow the reference file:line cited at each function (envs/multigrid/
+// multigrid.py, envs/multigrid/adversarial.py, envs/wrappers/*).  The functions are
+// __host__ __device__ so tests/hostsim can run the identical code on the CPU (debugging and
+// sanitizers only — the product path has no CPU mode).
+#pragma once
+#include <stdint.h>
+#include "../../include/dcd_hip.h"
+
+#if defined(__HIPCC__)
+#define DCD_HD __host__ __device__ __forceinline__
+#define DCD_HDM __host__ __device__ __forceinline__
+#else
+#define DCD_HD static inline
+#define DCD_HDM inline
+#endif
+
+namespace dcd {
+
+constexpr int REC_BYTES = 256;
+constexpr int ROW = 16;
+constexpr int DYN = 240;
+constexpr uint8_t NOPOS = 0xFF;
+
+enum : uint8_t { C_NONE = 0, C_WALL0 = 1, C_FLOOR0 = 7, C_KEY0 = 13, C_BALL0 = 19, C_BOX0 = 25,
+                 C_GOAL = 31, C_LAVA = 32, C_AGENT0 = 33, C_DOOR0 = 37, C_END = 55 };
+constexpr uint8_t C_WALL_GREY = C_WALL0 + 5;
+
+// level-constant parameters shared by every env of a handle (kernel argument, by value)
+struct Params {
+  int32_t B, S, V, max_steps, max_episode_steps, n_clutter, resample_n_clutter, choose_goal_last,
+      random_z_dim, n_editor_actions, fixed_environment;
+  float goal_noise;
+  uint32_t engine_seed;
+};
+
+// ---------------------------------------------------------------- Philox4x32-10 (Salmon et al. SC'11)
+DCD_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+DCD_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                          uint32_t out[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0, hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ---------------------------------------------------------------- packed codes
+DCD_HD bool is_wall(uint8_t c) { return c >= C_WALL0 && c < C_FLOOR0; }
+DCD_HD bool is_agent(uint8_t c) { return c >= C_AGENT0 && c < C_DOOR0; }
+DCD_HD bool is_door(uint8_t c) { return c >= C_DOOR0 && c < C_END; }
+DCD_HD bool can_overlap(uint8_t c) {   // gym_minigrid WorldObj.can_overlap: Goal, Floor, Lava, open Door
+  return (c >= C_FLOOR0 && c < C_KEY0) || c == C_GOAL || c == C_LAVA || (is_door(c) && ((c - C_DOOR0) % 3) == 0);
+}
+DCD_HD bool can_pickup(uint8_t c) { return c >= C_KEY0 && c < C_GOAL; }   // Key, Ball, Box
+// WorldObj.encode / Agent.encode (multigrid.py:138-140); None -> (1,0,0) (Grid.encode)
+DCD_HD uint32_t enc3(uint8_t c) {     // type | colour<<8 | state<<16
+  if (c == C_NONE) return DCD_OBJ_EMPTY;
+  if (c < C_FLOOR0) return DCD_OBJ_WALL | ((uint32_t)(c - C_WALL0) << 8);
+  if (c < C_KEY0) return DCD_OBJ_FLOOR | ((uint32_t)(c - C_FLOOR0) << 8);
+  if (c < C_BALL0) return DCD_OBJ_KEY | ((uint32_t)(c - C_KEY0) << 8);
+  if (c < C_BOX0) return DCD_OBJ_BALL | ((uint32_t)(c - C_BALL0) << 8);
+  if (c < C_GOAL) return DCD_OBJ_BOX | ((uint32_t)(c - C_BOX0) << 8);
+  if (c == C_GOAL) return DCD_OBJ_GOAL | (1u << 8);
+  if (c == C_LAVA) return DCD_OBJ_LAVA;
+  if (c < C_DOOR0) return DCD_OBJ_AGENT | ((uint32_t)(c - C_AGENT0) << 16);
+  uint32_t d = c - C_DOOR0;
+  return DCD_OBJ_DOOR | ((d / 3) << 8) | ((d % 3) << 16);
+}
+// WorldObj.decode (multigrid.py:72-107); returns false on bytes the reference raises on
+DCD_HD bool dec3(uint8_t t, uint8_t col, uint8_t s, uint8_t* code) {
+  *code = C_NONE;
+  if (t > DCD_OBJ_AGENT) return false;
+  if (t != DCD_OBJ_AGENT && col > 5) return false;
+  switch (t) {
+    case DCD_OBJ_UNSEEN: case DCD_OBJ_EMPTY: return true;
+    case DCD_OBJ_WALL: *code = C_WALL0 + col; return true;
+    case DCD_OBJ_FLOOR: *code = C_FLOOR0 + col; return true;
+    case DCD_OBJ_KEY: *code = C_KEY0 + col; return true;
+    case DCD_OBJ_BALL: *code = C_BALL0 + col; return true;
+    case DCD_OBJ_BOX: *code = C_BOX0 + col; return true;
+    case DCD_OBJ_DOOR: *code = C_DOOR0 + col * 3 + (s == 0 ? 0 : (s == 2 ? 2 : 1)); return true;
+    case DCD_OBJ_GOAL: *code = C_GOAL; return true;
+    case DCD_OBJ_LAVA: *code = C_LAVA; return true;
+    default: *code = C_AGENT0 + (s & 3); return s < 4;   // Agent(dir=state); dir>3 would break dir_vec
+  }
+}
+
+// ---------------------------------------------------------------- env view over the record bytes
+struct Env {
+  uint8_t* r;          // 256-byte record (LDS or host memory), row pitch 16
+  uint32_t seed;       // Philox key word 0 (per-env seed)
+  uint32_t err;        // DCD_ERR_* bits raised by this call
+  // write-back bookkeeping for the hot step: cells changed (<=2) or everything
+  uint16_t doff[2];
+  int nd;
+  bool full_dirty;
+
+  DCD_HDM uint8_t& cell(int x, int y) { return r[y * ROW + x]; }
+  DCD_HDM uint8_t& sb(int k) { return r[k * ROW + 15]; }
+  DCD_HDM void set_cell(int x, int y, uint8_t c) {
+    r[y * ROW + x] = c;
+    if (!full_dirty) { if (nd < 2) doff[nd++] = (uint16_t)(y * ROW + x); else full_dirty = true; }
+  }
+  DCD_HDM uint16_t get16(int o) const { return (uint16_t)(r[o] | (r[o + 1] << 8)); }
+  DCD_HDM void put16(int o, uint32_t v) { r[o] = (uint8_t)v; r[o + 1] = (uint8_t)(v >> 8); }
+  // dyn accessors
+  DCD_HDM uint8_t& ax() { return r[DYN + 0]; }
+  DCD_HDM uint8_t& ay() { return r[DYN + 1]; }
+  DCD_HDM uint8_t& adir() { return r[DYN + 2]; }
+  DCD_HDM uint8_t& carrying() { return r[DYN + 3]; }
+  DCD_HDM uint8_t& done() { return r[DYN + 10]; }
+  DCD_HDM bool has_pos() { return r[DYN + 0] != NOPOS; }
+  DCD_HDM float ep_ret() const { uint32_t u = r[DYN + 12] | (r[DYN + 13] << 8) | (r[DYN + 14] << 16) | ((uint32_t)r[DYN + 15] << 24);
+                                float f; __builtin_memcpy(&f, &u, 4); return f; }
+  DCD_HDM void set_ep_ret(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4);
+                                    r[DYN + 12] = (uint8_t)u; r[DYN + 13] = (uint8_t)(u >> 8); r[DYN + 14] = (uint8_t)(u >> 16); r[DYN + 15] = (uint8_t)(u >> 24); }
+  // rng draw counter lives in SB8..11
+  DCD_HDM uint32_t ctr() { return sb(8) | (sb(9) << 8) | (sb(10) << 16) | ((uint32_t)sb(11) << 24); }
+  DCD_HDM void set_ctr(uint32_t v) { sb(8) = (uint8_t)v; sb(9) = (uint8_t)(v >> 8); sb(10) = (uint8_t)(v >> 16); sb(11) = (uint8_t)(v >> 24); full_dirty = true; }
+};
+
+DCD_HD Env make_env(uint8_t* rec, uint32_t seed) {
+  Env e; e.r = rec; e.seed = seed; e.err = 0; e.nd = 0; e.full_dirty = false; e.doff[0] = e.doff[1] = 0; return e;
+}
+
+DCD_HD uint32_t rand_u32(Env& e, const Params& p) {
+  uint32_t o[4], n = e.ctr();
+  philox4x32_10(n, 0, 0, 0, e.seed, p.engine_seed, o);
+  e.set_ctr(n + 1);
+  return o[0];
+}
+DCD_HD int randint(Env& e, const Params& p, int n) { return (int)mulhi32(rand_u32(e, p), (uint32_t)n); }
+DCD_HD float uniform01(Env& e, const Params& p) { return (float)(rand_u32(e, p) >> 8) * (1.0f / 16777216.0f); }
+
+// generate_random_z (adversarial.py:449-450): always consumes 13 counters
+DCD_HD void generate_random_z(Env& e, const Params& p, float* z) {
+  uint32_t n = e.ctr();
+  for (int q = 0; q < 13; ++q) {
+    uint32_t o[4];
+    philox4x32_10(n + q, 0, 0, 0, e.seed, p.engine_seed, o);
+    if (z) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { int k = q * 4 + w; if (k < p.random_z_dim) z[k] = (float)(o[w] >> 8) * (1.0f / 16777216.0f); }
+    }
+  }
+  e.set_ctr(n + 13);
+}
+
+// metrics live outside the record (int32[4] per env): n_clutter_placed, passable, shortest path, distance
+struct Metrics { int32_t n_clutter_placed, passable, shortest_path_length, distance_to_goal; };
+DCD_HD void reset_metrics(Metrics& m, const Params& p) {           // adversarial.py:184-188
+  m.distance_to_goal = -1; m.n_clutter_placed = 0; m.passable = -1;
+  m.shortest_path_length = (p.S - 2) * (p.S - 2) + 1;
+}
+
+// _gen_grid (adversarial.py:166-172)
+DCD_HD void gen_grid(Env& e, const Params& p) {
+  const int S = p.S;
+  for (int y = 0; y < S; ++y)
+    for (int x = 0; x < S; ++x)
+      e.cell(x, y) = (x == 0 || y == 0 || x == S - 1 || y == S - 1) ? C_WALL_GREY : C_NONE;
+  e.full_dirty = true;
+}
+
+// place_obj with top=None,size=None (multigrid.py:565-632): uniform over None cells != agent_pos,
+// drawn as the k-th such cell in row-major order.  code==C_NONE: position only (place_one_agent).
+DCD_HD bool place_uniform(Env& e, const Params& p, uint8_t code, int* px, int* py) {
+  const int S = p.S;
+  const int ex = e.has_pos() ? e.ax() : -1, ey = e.ay();
+  int n = 0;
+  for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x)
+    n += (e.cell(x, y) == C_NONE && !(x == ex && y == ey)) ? 1 : 0;
+  if (n == 0) { e.err |= DCD_ERR_NO_FREE_CELL; return false; }
+  int k = randint(e, p, n);
+  for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x) {
+    if (e.cell(x, y) != C_NONE || (x == ex && y == ey)) continue;
+    if (k-- == 0) { if (code != C_NONE) e.set_cell(x, y, code); *px = x; *py = y; return true; }
+  }
+  return false;
+}
+
+// place_agent_at_pos (multigrid.py:668-681); rand_dir=True means dir := 0 (:670-672)
+DCD_HD void place_agent_at_pos(Env& e, int x, int y, bool rand_dir) {
+  e.ax() = (uint8_t)x; e.ay() = (uint8_t)y;
+  if (rand_dir) e.adir() = 0;
+  e.set_cell(x, y, C_AGENT0 + e.adir());
+}
+// place_one_agent with top=None (multigrid.py:651-666)
+DCD_HD bool place_one_agent(Env& e, const Params& p, bool rand_dir, int* px, int* py) {
+  e.ax() = NOPOS;
+  if (!place_uniform(e, p, C_NONE, px, py)) return false;
+  place_agent_at_pos(e, *px, *py, rand_dir);
+  return true;
+}
+DCD_HD void reset_agent_status(Env& e) {                                  // adversarial.py:231-236
+  e.ax() = NOPOS; e.adir() = e.sb(2); e.done() = 0; e.carrying() = C_NONE;
+}
+// AdversarialEnv.reset_agent (adversarial.py:238-269); TimeLimit counter is the caller's job
+DCD_HD void reset_agent(Env& e) {
+  if (e.has_pos()) e.set_cell(e.ax(), e.ay(), C_NONE);
+  reset_agent_status(e);
+  e.put16(DYN + 4, 0);                                                      // step_count
+  if (e.sb(0) == NOPOS) { e.err |= DCD_ERR_NO_START_POS; return; }
+  place_agent_at_pos(e, e.sb(0), e.sb(1), false);
+}
+
+// compute_metrics (adversarial.py:190-192,407-447): wall count + BFS on the interior graph with
+// wall nodes removed.  Bit-board BFS: one uint16 row mask per interior row (<= 13x13).
+DCD_HD void compute_metrics(Env& e, const Params& p, Metrics& m) {
+  const int I = p.S - 2;
+  uint16_t fr[13], rc[13];
+  int nw = 0;
+#pragma unroll
+  for (int y = 0; y < 13; ++y) {
+    uint16_t f = 0;
+    if (y < I) for (int x = 0; x < I; ++x) { bool w = is_wall(e.cell(x + 1, y + 1)); nw += w; f |= (uint16_t)((w ? 0 : 1) << x); }
+    fr[y] = f; rc[y] = 0;
+  }
+  m.n_clutter_placed = nw;
+  if (e.sb(0) == NOPOS || e.sb(3) == NOPOS) return;
+  const int sx = e.sb(0) - 1, sy = e.sb(1) - 1, gx = e.sb(3) - 1, gy = e.sb(4) - 1;
+  int dx = gx - sx, dy = gy - sy;
+  m.distance_to_goal = (dx < 0 ? -dx : dx) + (dy < 0 ? -dy : dy);
+#pragma unroll
+  for (int y = 0; y < 13; ++y) if (y == sy) rc[y] = (uint16_t)(1u << sx);
+  int dist = 0, found = (sx == gx && sy == gy) ? 1 : 0;
+  for (int it = 0; it < 169 && !found; ++it) {
+    uint16_t nr[13]; bool changed = false;
+#pragma unroll
+    for (int y = 0; y < 13; ++y) {
+      uint16_t v = rc[y];
+      uint16_t up = (y > 0) ? rc[y - 1] : 0, dn = (y < 12) ? rc[y + 1] : 0;
+      uint16_t x = (uint16_t)((v | (uint16_t)(v << 1) | (v >> 1) | up | dn) & fr[y]);
+      changed |= (x != v); nr[y] = x;
+    }
+    if (!changed) break;
+#pragma unroll
+    for (int y = 0; y < 13; ++y) rc[y] = nr[y];
+    dist = it + 1;
+    uint16_t grow = 0;
+#pragma unroll
+    for (int y = 0; y < 13; ++y) if (y == gy) grow = rc[y];
+    found = (grow >> gx) & 1;
+  }
+  m.passable = found;
+  m.shortest_path_length = found ? dist : I * I + 1;
+}
+
+// AdversarialEnv.reset (adversarial.py:194-229): z == nullptr still consumes the draws
+DCD_HD void env_reset(Env& e, const Params& p, Metrics& m, float* z) {
+  e.put16(DYN + 4, 0); e.sb(6) = 0;
+  if (p.resample_n_clutter) e.sb(5) &= (uint8_t)~1u;
+  e.sb(2) = (uint8_t)randint(e, p, 4);
+  reset_agent_status(e);
+  e.sb(0) = NOPOS; e.sb(3) = NOPOS;
+  reset_metrics(m, p);
+  gen_grid(e, p);
+  generate_random_z(e, p, z);
+}
+
+DCD_HD void remove_wall(Env& e, Metrics& m, int x, int y) {               // adversarial.py:399-405
+  if (is_wall(e.cell(x, y))) { e.set_cell(x, y, C_NONE); m.n_clutter_placed -= 1; }
+}
+
+// step_adversary (adversarial.py:452-539); returns done
+DCD_HD bool env_step_adversary(Env& e, const Params& p, Metrics& m, int64_t loc, float* z) {
+  const int I = p.S - 2, dim = I * I;
+  if (loc < 0 || loc >= dim) { e.err |= DCD_ERR_BAD_ADV_ACTION; loc = 0; }
+  if (p.resample_n_clutter && !(e.sb(5) & 1)) {                           // :469-472
+    int nc = (int)(((double)loc / (double)dim) * (double)p.n_clutter);
+    e.sb(7) = (uint8_t)(nc + 2); e.sb(5) |= 1;
+  }
+  const int cnt = e.sb(6), mx = e.sb(7);
+  if (cnt < mx) {
+    const int x = (int)(loc % I) + 1, y = (int)(loc / I) + 1;
+    const bool choose_goal = p.choose_goal_last ? (cnt == mx - 2) : (cnt == 0);
+    const bool choose_agent = p.choose_goal_last ? (cnt == mx - 1) : (cnt == 1);
+    if (choose_goal) {
+      bool noisy = false;
+      if (p.goal_noise > 0.0f) noisy = uniform01(e, p) < p.goal_noise;     // :493
+      if (noisy) {
+        int px, py;
+        if (place_uniform(e, p, C_GOAL, &px, &py)) { e.sb(3) = (uint8_t)px; e.sb(4) = (uint8_t)py; }
+      } else {
+        remove_wall(e, m, x, y);
+        e.set_cell(x, y, C_GOAL);
+        e.sb(3) = (uint8_t)x; e.sb(4) = (uint8_t)y;
+      }
+    } else if (choose_agent) {
+      remove_wall(e, m, x, y);
+      if (e.cell(x, y) != C_NONE) {                                        // goal already here :505
+        int px, py;
+        if (place_one_agent(e, p, false, &px, &py)) { e.sb(0) = (uint8_t)px; e.sb(1) = (uint8_t)py; }
+      } else {
+        e.sb(0) = (uint8_t)x; e.sb(1) = (uint8_t)y;
+        place_agent_at_pos(e, x, y, false);
+      }
+    } else if (e.cell(x, y) == C_NONE) {                                   // :517-520
+      e.set_cell(x, y, C_WALL_GREY); m.n_clutter_placed += 1;
+    }
+  }
+  e.sb(6) = (uint8_t)(cnt + 1);
+  bool done = false;
+  if (cnt + 1 >= p.n_clutter + 2) { done = true; reset_metrics(m, p); compute_metrics(e, p, m); }   // :525
+  generate_random_z(e, p, z);
+  e.full_dirty = true;
+  return done;
+}
+
+// reset_to_encoding body after reset() (adversarial.py:290-294; multigrid.py:264-280)
+DCD_HD void env_set_encoding(Env& e, const Params& p, Metrics& m, const uint8_t* enc) {
+  const int S = p.S;
+  for (int i = 0; i < S; ++i) for (int j = 0; j < S; ++j) {
+    const uint8_t* c = enc + (i * S + j) * 3;
+    uint8_t code;
+    if (!dec3(c[0], c[1], c[2], &code)) { e.err |= DCD_ERR_BAD_ENCODING; code = C_NONE; }
+    if (is_agent(code)) { e.sb(0) = (uint8_t)i; e.sb(1) = (uint8_t)j; }
+    else if (code == C_GOAL) { e.sb(3) = (uint8_t)i; e.sb(4) = (uint8_t)j; }
+    e.cell(i, j) = code;
+  }
+  e.full_dirty = true;
+  compute_metrics(e, p, m);
+  reset_agent(e);
+}
+
+// reset_random (adversarial.py:541-581)
+DCD_HD void env_reset_random(Env& e, const Params& p, Metrics& m) {
+  if (p.fixed_environment) e.set_ctr(0);
+  e.put16(DYN + 4, 0); e.sb(6) = 0;
+  reset_agent_status(e);
+  e.sb(0) = NOPOS; e.sb(3) = NOPOS;
+  reset_metrics(m, p);
+  gen_grid(e, p);
+  int px, py;
+  if (place_uniform(e, p, C_GOAL, &px, &py)) { e.sb(3) = (uint8_t)px; e.sb(4) = (uint8_t)py; }
+  e.sb(2) = (uint8_t)randint(e, p, 4);
+  if (place_one_agent(e, p, false, &px, &py)) { e.sb(0) = (uint8_t)px; e.sb(1) = (uint8_t)py; }
+  int nc;
+  if (p.resample_n_clutter) { nc = randint(e, p, p.n_clutter); e.sb(7) = (uint8_t)(nc + 2); e.sb(5) |= 1; }
+  else nc = p.n_clutter / 2;
+  for (int k = 0; k < nc; ++k) place_uniform(e, p, C_WALL_GREY, &px, &py);
+  compute_metrics(e, p, m);
+  reset_agent(e);
+}
+
+// mutate_level (adversarial.py:317-397)
+DCD_HD void env_mutate_level(Env& e, const Params& p, Metrics& m, int num_edits) {
+  const int I = p.S - 2, ntiles = I * I;
+  uint8_t locs[64], acts[64]; int nloc = 0;
+  if (num_edits > 64) num_edits = 64;
+  for (int k = 0; k < num_edits; ++k) {
+    int l = randint(e, p, ntiles); bool dup = false;
+    for (int q = 0; q < nloc; ++q) dup |= (locs[q] == l);
+    if (!dup) locs[nloc++] = (uint8_t)l;
+  }
+  for (int k = 0; k < nloc; ++k) acts[k] = (uint8_t)randint(e, p, p.n_editor_actions);
+  uint16_t fm[13];                                  // free_mask rows (:332-334)
+#pragma unroll
+  for (int y = 0; y < 13; ++y) {
+    uint16_t f = 0;
+    if (y < I) for (int x = 0; x < I; ++x) f |= (uint16_t)((is_wall(e.cell(x + 1, y + 1)) ? 0 : 1) << x);
+    fm[y] = f;
+  }
+  auto fm_set = [&](int x, int y, bool v) {         // interior coords
+#pragma unroll
+    for (int yy = 0; yy < 13; ++yy) if (yy == y) fm[yy] = v ? (uint16_t)(fm[yy] | (1u << x)) : (uint16_t)(fm[yy] & ~(1u << x));
+  };
+  if (e.sb(0) != NOPOS) fm_set(e.sb(0) - 1, e.sb(1) - 1, false);
+  if (e.sb(3) != NOPOS) fm_set(e.sb(3) - 1, e.sb(4) - 1, false);
+  for (int k = 0; k < nloc; ++k) {
+    const int x = locs[k] % I + 1, y = locs[k] / I + 1;
+    remove_wall(e, m, x, y);                         // _clean_loc (:296-306)
+    uint8_t o = e.cell(x, y);
+    if (o == C_GOAL) e.sb(3) = NOPOS; else if (is_agent(o)) e.sb(0) = NOPOS;
+    e.set_cell(x, y, C_NONE);
+    int a = acts[k];                                 // 0 '-', 1 '.', then 'g' (3 actions) or 'a','g' (4)
+    const bool act_agent = (p.n_editor_actions == 4 && a == 2);
+    const bool act_goal = (a >= 2 && !act_agent);
+    if (a == 0) { e.set_cell(x, y, C_WALL_GREY); m.n_clutter_placed += 1; fm_set(x - 1, y - 1, false); }
+    else if (a == 1) { fm_set(x - 1, y - 1, true); }
+    else if (act_agent) {
+      if (e.sb(0) != NOPOS) { e.set_cell(e.sb(0), e.sb(1), C_NONE); fm_set(e.sb(0) - 1, e.sb(1) - 1, true); }
+      place_agent_at_pos(e, x, y, true);
+      e.sb(0) = (uint8_t)x; e.sb(1) = (uint8_t)y; fm_set(x - 1, y - 1, false);
+    } else if (act_goal) {
+      if (e.sb(3) != NOPOS) { e.set_cell(e.sb(3), e.sb(4), C_NONE); fm_set(e.sb(3) - 1, e.sb(4) - 1, true); }
+      e.set_cell(x, y, C_GOAL);
+      e.sb(3) = (uint8_t)x; e.sb(4) = (uint8_t)y; fm_set(x - 1, y - 1, false);
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {             // goal, then agent (:370-388)
+    if (pass == 0 ? (e.sb(3) != NOPOS) : (e.sb(0) != NOPOS)) continue;
+    int n = 0;
+#pragma unroll
+    for (int y = 0; y < 13; ++y) n += __builtin_popcount((unsigned)fm[y]);
+    if (n == 0) { e.err |= DCD_ERR_NO_FREE_CELL; continue; }
+    int kk = randint(e, p, n), sx = -1, sy = -1;
+    for (int y = 0; y < I && sx < 0; ++y) {
+      uint16_t row = 0;
+#pragma unroll
+      for (int yy = 0; yy < 13; ++yy) if (yy == y) row = fm[yy];
+      for (int x = 0; x < I; ++x) if ((row >> x) & 1) { if (kk-- == 0) { sx = x; sy = y; break; } }
+    }
+    fm_set(sx, sy, false);
+    const int x = sx + 1, y = sy + 1;
+    if (pass == 0) { e.set_cell(x, y, C_GOAL); e.sb(3) = (uint8_t)x; e.sb(4) = (uint8_t)y; }
+    else { place_agent_at_pos(e, x, y, true); e.sb(0) = (uint8_t)x; e.sb(1) = (uint8_t)y; }
+  }
+  e.put16(DYN + 4, 0); e.sb(6) = 0;
+  reset_metrics(m, p);
+  compute_metrics(e, p, m);
+  reset_agent(e);
+  e.full_dirty = true;
+}
+
+// agent_is_done (multigrid.py:821-838)
+DCD_HD void agent_is_done(Env& e, const Params& p) {
+  e.set_cell(e.ax(), e.ay(), C_NONE);
+  e.done() = 1;
+  int px, py;
+  if (e.carrying() != C_NONE) { place_uniform(e, p, e.carrying(), &px, &py); e.carrying() = C_NONE; }
+  place_one_agent(e, p, true, &px, &py);
+}
+
+// step_one_agent (multigrid.py:866-941); returns the fp64 reward rounded to fp32 (obs_wrappers.py:179)
+DCD_HD double step_one_agent(Env& e, const Params& p, int action, int step_count) {
+  const int d = e.adir();
+  const int fx = e.ax() + ((d == 0) - (d == 2)), fy = e.ay() + ((d == 1) - (d == 3));   // DIR_TO_VEC
+  const bool ok = fx >= 0 && fx < p.S && fy >= 0 && fy < p.S;
+  if (!ok) e.err |= DCD_ERR_OUT_OF_GRID;
+  const uint8_t fwd = ok ? e.cell(fx, fy) : C_WALL_GREY;
+  double reward = 0.0;
+  switch (action) {
+    case DCD_ACT_LEFT: e.adir() = (uint8_t)((d + 3) & 3); e.set_cell(e.ax(), e.ay(), C_AGENT0 + e.adir()); break;
+    case DCD_ACT_RIGHT: e.adir() = (uint8_t)((d + 1) & 3); e.set_cell(e.ax(), e.ay(), C_AGENT0 + e.adir()); break;
+    case DCD_ACT_FORWARD:
+      if (!ok) break;
+      if (fwd == C_GOAL) {
+        agent_is_done(e, p);
+        reward = 1.0 - 0.9 * ((double)step_count / (double)p.max_steps);   // MiniGridEnv._reward
+      } else if (fwd == C_LAVA) {
+        agent_is_done(e, p);
+      } else if (fwd == C_NONE || can_overlap(fwd)) {                       // move_agent :840-853
+        e.set_cell(e.ax(), e.ay(), C_NONE);
+        e.ax() = (uint8_t)fx; e.ay() = (uint8_t)fy;
+        e.set_cell(fx, fy, C_AGENT0 + d);
+      }
+      break;
+    case DCD_ACT_PICKUP:
+      if (ok && can_pickup(fwd) && e.carrying() == C_NONE) { e.carrying() = fwd; e.set_cell(fx, fy, C_NONE); }
+      break;
+    case DCD_ACT_DROP:
+      if (ok && fwd == C_NONE && e.carrying() != C_NONE) { e.set_cell(fx, fy, e.carrying()); e.carrying() = C_NONE; }
+      break;
+    case DCD_ACT_TOGGLE:
+      if (ok && is_door(fwd)) {                                             // Door.toggle multigrid.py:113-123
+        const int dd = fwd - C_DOOR0, col = dd / 3, st = dd % 3;
+        if (st == 2) { if (e.carrying() == C_KEY0 + col) e.set_cell(fx, fy, C_DOOR0 + col * 3); }
+        else e.set_cell(fx, fy, C_DOOR0 + col * 3 + (st == 0 ? 1 : 0));
+      } else if (ok && fwd >= C_BOX0 && fwd < C_GOAL) {
+        e.set_cell(fx, fy, C_NONE);                                          // Box.toggle: contents (None)
+      }
+      break;
+    case DCD_ACT_DONE: break;
+    default: e.err |= DCD_ERR_BAD_ACTION; break;
+  }
+  return reward;
+}
+
+// gen_obs (multigrid.py:977-1055) via the closed-form view->world map of multigrid.py:1080-1093:
+//   world = agent + f*(V-1-vy) + r*(vx - V/2), f = DIR_TO_VEC[dir], r = (-f.y, f.x)
+// out: V*V*3 bytes indexed [vx][vy][c].  Out-of-grid cells render as Wall() (grey) (:330-334);
+// the agent's own cell shows the carried object or empty (:1009-1013); other Agent objects seen in
+// the view have their dir rotated with the view (rotate_left :308-314).
+DCD_HD void render_view(Env& e, const Params& p, uint8_t* out) {
+  const int V = p.V, S = p.S, d = e.adir();
+  const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3), rx = -fy, ry = fx;
+  const int ax = e.ax(), ay = e.ay(), h = V / 2;
+  for (int vx = 0; vx < V; ++vx) for (int vy = 0; vy < V; ++vy) {
+    const int wx = ax + fx * (V - 1 - vy) + rx * (vx - h), wy = ay + fy * (V - 1 - vy) + ry * (vx - h);
+    uint8_t c;
+    if (vx == h && vy == V - 1) c = e.carrying();
+    else if (wx < 0 || wx >= S || wy < 0 || wy >= S) c = C_WALL_GREY;
+    else { c = e.cell(wx, wy); if (is_agent(c)) c = (uint8_t)(C_AGENT0 + (((c - C_AGENT0) - (d + 1)) & 3)); }
+    const uint32_t t = enc3(c);
+    uint8_t* o = out + (vx * V + vy) * 3;
+    o[0] = (uint8_t)t; o[1] = (uint8_t)(t >> 8); o[2] = (uint8_t)(t >> 16);
+  }
+}
+
+struct StepResult { float reward; uint8_t done, info; float ep_ret; int32_t ep_len; bool have_term; };
+
+// worker.step_env ∘ TimeLimit.step ∘ MultiGridEnv.step ∘ VecMonitor.step_wait [∘ runner last-step rule].
+// term (V*V*3 bytes + 1 dir byte at term[V*V*3]) receives the pre-reset obs when have_term.
+DCD_HD StepResult env_step(Env& e, const Params& p, Metrics& m, bool& metrics_dirty, int64_t action64,
+                           int flags, uint8_t* term) {
+  StepResult r;
+  const int step_count = e.get16(DYN + 4) + 1;                             // multigrid.py:948
+  e.put16(DYN + 4, step_count);
+  const int action = (action64 < 0 || action64 > 6) ? 7 : (int)action64;
+  const double reward = step_one_agent(e, p, action, step_count);
+  bool done = e.done() >= 1;                                               // competitive, n_agents == 1
+  if (step_count >= p.max_steps) done = true;                             // :972-973
+  uint8_t info = 0; bool have_term = false;
+  if (p.max_episode_steps > 0) {                                           // time_limit.py:24-33
+    const int el = e.get16(DYN + 6) + 1;
+    e.put16(DYN + 6, el);
+    if (el >= p.max_episode_steps) {
+      info |= DCD_INFO_TRUNC_KEY; if (!done) info |= DCD_INFO_TRUNCATED;
+      have_term = true; done = true;
+    }
+  }
+  if (have_term) { render_view(e, p, term); term[p.V * p.V * 3] = e.adir(); }
+  if (done) {                                                              // parallel_wrappers.py:27-37
+    if (flags & DCD_STEP_RESET_RANDOM) { env_reset_random(e, p, m); metrics_dirty = true; }
+    reset_agent(e);
+    e.put16(DYN + 6, 0);                                                   // time_limit.py:39-49
+  }
+  // VecMonitor.step_wait (vec_monitor.py:60-85): eprets(f32) += rews(f64) is an fp64 add rounded to f32
+  float epr = (float)((double)e.ep_ret() + reward);
+  int epl = e.get16(DYN + 8) + 1;
+  r.ep_ret = 0.f; r.ep_len = 0;
+  if (done) { info |= DCD_INFO_EPISODE; r.ep_ret = epr; r.ep_len = epl; epr = 0.f; epl = 0; }
+  e.set_ep_ret(epr); e.put16(DYN + 8, epl);
+  if (flags & DCD_STEP_LAST) {                                             // adversarial_runner.py:521-530
+    if (!done) info |= DCD_INFO_CLIFFHANGER | DCD_INFO_TRUNC_KEY | DCD_INFO_TRUNCATED;
+    done = true;
+  }
+  r.reward = (float)reward; r.done = done; r.info = info;
+  r.have_term = have_term && (info & DCD_INFO_EPISODE);                    // runner inserts only then (:539-549)
+  return r;
+}
+
+}  // namespace dcd

@@ -1,0 +1,529 @@
+// mg_kernels.hip — MultiGrid engine kernels for gfx950 (MI355X) + their C ABI (include/dcd_hip.h).
+//
+// Mapping: one env per lane, one 64-lane wavefront per workgroup.  A wave owns 64 consecutive
+// 256-byte env records = 16 KiB of contiguous HBM: it pulls them with 16 fully coalesced
+// 1-KiB wave loads (16 B per lane) into LDS (row pitch 272 B: 16-B aligned for ds_write_b128,
+// 68 dwords so lanes spread over banks), then every lane works on ITS env purely out of LDS —
+// the front cell, the V×V neighbourhood gather and all writes are LDS traffic, so a step costs
+// exactly one dependent HBM round trip.  Results leave through LDS staging so that every global
+// store instruction of a wave is contiguous (obs tensors are [B, ...] row-major).
+// The hot step writes back only the 16-byte dynamic state plus the <=2 cells it changed; rare
+// paths (episode end, respawn, resets) write the whole record back.
+//
+// HBM bytes per env-step: read 256 (record) + 8 (action); write 16 (dyn)
+// + <=2 (cells) + obs 75+1 (u8) and/or 300+4 (f32) + reward 4 + done/info 2 + masks 12.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include "mg_env.h"
+#include "dcd_internal.h"
+
+using namespace dcd;
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int LP = 272;            // LDS pitch of one env record
+constexpr int MAX_OP = 152;        // staged u8 obs per env: V*V*3 + dir, padded (V<=7 -> 148)
+
+__device__ __forceinline__ int obs_pitch(int V) { return (V * V * 3 + 1 + 3) & ~3; }
+
+// ---- wave-cooperative record staging ------------------------------------------------------
+// rows: env index of each of the wave's `n` rows comes from env_of[row] (LDS int array)
+__device__ __forceinline__ void stage_in(uint8_t* lds, const uint8_t* __restrict__ rec, const int* env_of,
+                                         int n, int lane) {
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int q = k * WAVE + lane, row = q >> 4, c = q & 15;
+    if (row < n) {
+      const uint4 v = *reinterpret_cast<const uint4*>(rec + (size_t)env_of[row] * REC_BYTES + c * 16);
+      *reinterpret_cast<uint4*>(lds + row * LP + c * 16) = v;
+    }
+  }
+}
+__device__ __forceinline__ void stage_out(const uint8_t* lds, uint8_t* __restrict__ rec, const int* env_of,
+                                          int n, int lane) {
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const int q = k * WAVE + lane, row = q >> 4, c = q & 15;
+    if (row < n) {
+      const uint4 v = *reinterpret_cast<const uint4*>(lds + row * LP + c * 16);
+      *reinterpret_cast<uint4*>(rec + (size_t)env_of[row] * REC_BYTES + c * 16) = v;
+    }
+  }
+}
+
+// ---- coalesced emission of staged student observations --------------------------------------
+// sobs: [n][OP] bytes ([vx][vy][c] then dir).  Output row of staged row r is out_row0 + r.
+__device__ __forceinline__ void emit_student(const uint8_t* sobs, const float* lut, const DcdStudentObs& o,
+                                             size_t out_row0, int n, int V, int lane, const uint8_t* valid) {
+  const int VV = V * V, E = VV * 3, OP = obs_pitch(V);
+  if (o.image_u8) for (int f = lane; f < n * E; f += WAVE) {
+    const int row = f / E, el = f - row * E;
+    if (!valid || valid[row]) o.image_u8[out_row0 * E + f] = sobs[row * OP + el];
+  }
+  if (o.image_f32) for (int f = lane; f < n * E; f += WAVE) {
+    const int row = f / E, el = f - row * E, c = el / VV, rem = el - c * VV;
+    if (!valid || valid[row]) o.image_f32[out_row0 * E + f] = lut[sobs[row * OP + rem * 3 + c]];
+  }
+  if (lane < n && (!valid || valid[lane])) {
+    const uint8_t d = sobs[lane * OP + E];
+    if (o.dir_u8) o.dir_u8[out_row0 + lane] = d;
+    if (o.dir_f32) o.dir_f32[out_row0 + lane] = (float)d;
+  }
+}
+
+__device__ __forceinline__ void init_lut(float* lut, int lane) {
+  // VecPreprocessImageWrapper: image/10.0 in fp64, then .float() (obs_wrappers.py:90-91,96)
+  for (int k = lane; k < 256; k += WAVE) lut[k] = (float)((double)k / 10.0);
+}
+
+__device__ __forceinline__ void raise(uint32_t* errs, uint32_t bits, int env) {
+  if (bits) { atomicOr(&errs[0], bits); atomicMin(reinterpret_cast<int*>(&errs[1]), env); }
+}
+
+// =================================================================================== hot step
+struct StepArgs {
+  uint8_t* rec; const uint32_t* seed; Metrics* met; uint32_t* errs;
+  const int64_t* actions; int flags;
+  DcdStepOut out;
+  // fused random-action mode (dcd_mg_step_random)
+  int K; uint32_t action_seed, t0; int64_t env_index_base; unsigned long long* n_episodes;
+};
+
+template <bool RANDOM>
+__global__ void __launch_bounds__(WAVE) mg_step_kernel(Params p, StepArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVE * LP];
+  __shared__ __attribute__((aligned(16))) uint8_t sobs[WAVE * MAX_OP];
+  __shared__ __attribute__((aligned(16))) uint8_t sterm[WAVE * MAX_OP];
+  __shared__ uint8_t term_valid[WAVE];
+  __shared__ int env_of[WAVE];
+  __shared__ float lut[256];
+  const int lane = threadIdx.x, env0 = blockIdx.x * WAVE;
+  const int n = min(WAVE, p.B - env0), env = env0 + lane;
+  const int OP = obs_pitch(p.V), E = p.V * p.V * 3;
+  env_of[lane] = env;
+  init_lut(lut, lane);
+  __syncthreads();
+  stage_in(lds, a.rec, env_of, n, lane);
+  __syncthreads();
+
+  StepResult r; r.reward = 0.f; r.done = 0; r.info = 0; r.ep_ret = 0.f; r.ep_len = 0; r.have_term = false;
+  unsigned long long episodes = 0;
+  if (lane < n) {
+    Env e = make_env(lds + lane * LP, a.seed[env]);
+    Metrics m = {0, 0, 0, 0}; bool mdirty = false;
+    if (a.flags & DCD_STEP_RESET_RANDOM) m = a.met[env];
+    const int K = RANDOM ? a.K : 1;
+    for (int k = 0; k < K; ++k) {
+      int64_t act;
+      if (RANDOM) {
+        uint32_t o[4];
+        philox4x32_10(a.t0 + k, 0, 0, 0, a.action_seed, (uint32_t)(a.env_index_base + env), o);
+        act = (int64_t)mulhi32(o[0], 7u);
+      } else act = a.actions[env];
+      const int fl = (RANDOM && k != K - 1) ? (a.flags & ~DCD_STEP_LAST) : a.flags;
+      r = env_step(e, p, m, mdirty, act, fl, sterm + lane * OP);
+      if (RANDOM) episodes += (r.info & DCD_INFO_EPISODE) ? 1 : 0;
+    }
+    // post-reset observation
+    if (e.has_pos()) { render_view(e, p, sobs + lane * OP); sobs[lane * OP + E] = e.adir(); }
+    else for (int i = 0; i <= E; ++i) sobs[lane * OP + i] = 0;
+    term_valid[lane] = r.have_term ? 1 : 0;
+    // write-back: dyn always; cells by dirty list or whole record
+    uint8_t* g = a.rec + (size_t)env * REC_BYTES;
+    *reinterpret_cast<uint4*>(g + DYN) = *reinterpret_cast<const uint4*>(e.r + DYN);
+    if (e.full_dirty) {
+#pragma unroll 5
+      for (int y = 0; y < 15; ++y) *reinterpret_cast<uint4*>(g + y * ROW) = *reinterpret_cast<const uint4*>(e.r + y * ROW);
+    } else {
+      if (e.nd > 0) g[e.doff[0]] = e.r[e.doff[0]];
+      if (e.nd > 1) g[e.doff[1]] = e.r[e.doff[1]];
+    }
+    if (mdirty) a.met[env] = m;
+    raise(a.errs, e.err, env);
+    const DcdStepOut& o = a.out;
+    if (o.reward) o.reward[env] = r.reward;
+    if (o.done) o.done[env] = r.done;
+    if (o.info) o.info[env] = r.info;
+    if (o.ep_ret) o.ep_ret[env] = r.ep_ret;
+    if (o.ep_len) o.ep_len[env] = r.ep_len;
+    if (o.masks) o.masks[env] = r.done ? 0.f : 1.f;                                      // runner :566-573
+    if (o.bad_masks) o.bad_masks[env] = (r.info & DCD_INFO_TRUNC_KEY) ? 0.f : 1.f;
+    if (o.cliffhanger_masks) o.cliffhanger_masks[env] = (r.info & DCD_INFO_CLIFFHANGER) ? 0.f : 1.f;
+  } else term_valid[lane] = 0;
+  __syncthreads();
+  emit_student(sobs, lut, a.out.obs, (size_t)env0, n, p.V, lane, nullptr);
+  const unsigned long long any_term = __ballot(term_valid[lane] != 0);
+  if (any_term) emit_student(sterm, lut, a.out.term_obs, (size_t)env0, n, p.V, lane, term_valid);
+  if (RANDOM && a.n_episodes) {
+    for (int off = 32; off > 0; off >>= 1) episodes += __shfl_down(episodes, off);
+    if (lane == 0 && episodes) atomicAdd(a.n_episodes, episodes);
+  }
+}
+
+// =================================================================================== level ops
+enum LevelOp { OP_RESET = 0, OP_STEP_ADV, OP_RESET_AGENT, OP_RESET_RANDOM, OP_SET_ENCODING, OP_REPLAY, OP_MUTATE,
+               OP_READ_ENC };
+
+struct LevelArgs {
+  uint8_t* rec; const uint32_t* seed; Metrics* met; uint32_t* errs;
+  const int32_t* idx; int n_rows;                 // rows -> env (nullptr: identity over B)
+  const int64_t* loc;                             // OP_STEP_ADV [B]; OP_REPLAY actions [n,max_len]
+  const int32_t* lens; int max_len;               // OP_REPLAY
+  const uint8_t* enc;                             // OP_SET_ENCODING [n,S,S,3]
+  int num_edits;                                  // OP_MUTATE
+  DcdAdvObs adv; uint8_t* adv_done;               // teacher outputs
+  DcdStudentObs stu;                              // student outputs
+  uint8_t* enc_out;                               // OP_READ_ENC [B,S,S,3]
+};
+
+template <int OP>
+__global__ void __launch_bounds__(WAVE) mg_level_kernel(Params p, LevelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVE * LP];
+  __shared__ __attribute__((aligned(16))) uint8_t sobs[WAVE * MAX_OP];
+  __shared__ int env_of[WAVE];
+  __shared__ float lut[256];
+  const int lane = threadIdx.x, row0 = blockIdx.x * WAVE;
+  const int n = min(WAVE, a.n_rows - row0), row = row0 + lane;
+  const int S = p.S, OPI = obs_pitch(p.V), E = p.V * p.V * 3;
+  int env = -1;
+  if (lane < n) env = a.idx ? a.idx[row] : row;
+  env_of[lane] = env;
+  init_lut(lut, lane);
+  __syncthreads();
+  stage_in(lds, a.rec, env_of, n, lane);
+  __syncthreads();
+
+  constexpr bool ADV_OUT = (OP == OP_RESET || OP == OP_STEP_ADV || OP == OP_READ_ENC);
+  float z[52];
+  bool done = false;
+  if (lane < n) {
+    Env e = make_env(lds + lane * LP, a.seed[env]);
+    Metrics m = a.met[env];
+    float* zp = (ADV_OUT && a.adv.random_z) ? z : nullptr;
+    if (OP == OP_RESET) {
+      env_reset(e, p, m, zp);
+      e.put16(DYN + 6, 0);                          // TimeLimit.reset (time_limit.py:35-37)
+      e.set_ep_ret(0.f); e.put16(DYN + 8, 0);       // VecMonitor.reset (vec_monitor.py:36-40)
+    } else if (OP == OP_STEP_ADV) {
+      done = env_step_adversary(e, p, m, a.loc[env], zp);
+    } else if (OP == OP_RESET_AGENT) {
+      reset_agent(e);
+      e.put16(DYN + 6, 0);                          // time_limit.py:47-49
+      e.set_ep_ret(0.f); e.put16(DYN + 8, 0);       // vec_monitor.py:42-46
+    } else if (OP == OP_RESET_RANDOM) {
+      env_reset_random(e, p, m);
+      e.put16(DYN + 6, 0);                          // time_limit.py:39-41
+      e.set_ep_ret(0.f); e.put16(DYN + 8, 0);       // vec_monitor.py:48-52
+    } else if (OP == OP_SET_ENCODING) {
+      env_reset(e, p, m, nullptr);                  // adversarial.py:272
+      e.put16(DYN + 6, 0);                          // time_limit.py:43-45
+      env_set_encoding(e, p, m, a.enc + (size_t)row * S * S * 3);
+    } else if (OP == OP_REPLAY) {
+      env_reset(e, p, m, nullptr);
+      e.put16(DYN + 6, 0);
+      const int L = a.lens[row];
+      if (p.resample_n_clutter) e.sb(7) = (uint8_t)L;                       // adversarial.py:277-278
+      for (int k = 0; k < L; ++k)
+        if (env_step_adversary(e, p, m, a.loc[(size_t)row * a.max_len + k], nullptr)) reset_agent(e);   // :280-283
+    } else if (OP == OP_MUTATE) {
+      env_mutate_level(e, p, m, a.num_edits);
+    }
+    if (OP != OP_READ_ENC) {
+      a.met[env] = m;
+      raise(a.errs, e.err, env);
+    }
+    if (!ADV_OUT) {
+      if (e.has_pos()) { render_view(e, p, sobs + lane * OPI); sobs[lane * OPI + E] = e.adir(); }
+      else for (int i = 0; i <= E; ++i) sobs[lane * OPI + i] = 0;
+    } else if (OP != OP_READ_ENC) {
+      if (a.adv.time_step) a.adv.time_step[env] = (float)e.sb(6);
+      if (a.adv.random_z) for (int k = 0; k < p.random_z_dim; ++k) a.adv.random_z[(size_t)env * p.random_z_dim + k] = z[k];
+      if (a.adv_done) a.adv_done[env] = done ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (OP != OP_READ_ENC) stage_out(lds, a.rec, env_of, n, lane);
+  if (ADV_OUT) {
+    // full-grid observation, [x][y][c] u8 and CHW fp32/10 — contiguous per wave (identity rows only)
+    const int G = S * S * 3;
+    uint8_t* u8 = (OP == OP_READ_ENC) ? a.enc_out : a.adv.image_u8;
+    if (u8) for (int f = lane; f < n * G; f += WAVE) {
+      const int r = f / G, el = f - r * G, cell = el / 3, c = el - cell * 3, x = cell / S, y = cell - x * S;
+      u8[(size_t)row0 * G + f] = (uint8_t)(enc3(lds[r * LP + y * ROW + x]) >> (8 * c));
+    }
+    if (OP != OP_READ_ENC && a.adv.image_f32) for (int f = lane; f < n * G; f += WAVE) {
+      const int r = f / G, el = f - r * G, c = el / (S * S), cell = el - c * S * S, x = cell / S, y = cell - x * S;
+      a.adv.image_f32[(size_t)row0 * G + f] = lut[(uint8_t)(enc3(lds[r * LP + y * ROW + x]) >> (8 * c))];
+    }
+  } else {
+    emit_student(sobs, lut, a.stu, (size_t)row0, n, p.V, lane, nullptr);
+  }
+}
+
+__global__ void set_seed_kernel(uint8_t* rec, uint32_t* seed, const int64_t* seeds, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  seed[i] = (uint32_t)seeds[i];
+  uint8_t* r = rec + (size_t)i * REC_BYTES;        // draw counter := 0 (SB8..11)
+  r[8 * ROW + 15] = 0; r[9 * ROW + 15] = 0; r[10 * ROW + 15] = 0; r[11 * ROW + 15] = 0;
+}
+
+__global__ void init_records_kernel(Params p, uint8_t* rec, uint32_t* seed, Metrics* met, long long base) {
+  // MultiGridEnv.__init__ -> reset() (multigrid.py:463): every env starts as an empty walled grid
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.B) return;
+  uint8_t* r = rec + (size_t)i * REC_BYTES;
+  for (int k = 0; k < REC_BYTES; ++k) r[k] = 0;
+  seed[i] = (uint32_t)(base + i);
+  Env e = make_env(r, seed[i]);
+  e.sb(7) = (uint8_t)(p.n_clutter + 2);             // adversary_max_steps (adversarial.py:107)
+  Metrics m;
+  env_reset(e, p, m, nullptr);
+  met[i] = m;
+}
+
+__global__ void get_state_kernel(Params p, const uint8_t* rec, int32_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.B) return;
+  uint8_t tmp[REC_BYTES];
+  for (int k = 0; k < REC_BYTES; ++k) tmp[k] = rec[(size_t)i * REC_BYTES + k];
+  Env e = make_env(tmp, 0);
+  int32_t* o = out + (size_t)i * 16;
+  o[0] = e.has_pos() ? e.ax() : -1; o[1] = e.has_pos() ? e.ay() : -1; o[2] = e.adir();
+  o[3] = e.carrying() ? (int32_t)enc3(e.carrying()) : 0;
+  o[4] = e.get16(DYN + 4); o[5] = e.get16(DYN + 6); o[6] = e.get16(DYN + 8);
+  float f = e.ep_ret(); memcpy(&o[7], &f, 4);
+  o[8] = e.sb(0) != NOPOS ? e.sb(0) : -1; o[9] = e.sb(0) != NOPOS ? e.sb(1) : -1; o[10] = e.sb(2);
+  o[11] = e.sb(3) != NOPOS ? e.sb(3) : -1; o[12] = e.sb(3) != NOPOS ? e.sb(4) : -1;
+  o[13] = e.sb(6); o[14] = e.sb(7); o[15] = (int32_t)e.ctr();
+}
+
+__global__ void get_metrics_kernel(int B, const Metrics* met, int32_t* ncl, int32_t* pas, int32_t* spl, int32_t* dist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const Metrics m = met[i];
+  if (ncl) ncl[i] = m.n_clutter_placed;
+  if (pas) pas[i] = m.passable;
+  if (spl) spl[i] = m.shortest_path_length;
+  if (dist) dist[i] = m.distance_to_goal;
+}
+
+__global__ void random_actions_kernel(int64_t* actions, int B, long long base, uint32_t seed, uint32_t t, int num_actions) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  uint32_t o[4];
+  philox4x32_10(t, 0, 0, 0, seed, (uint32_t)(base + i), o);
+  actions[i] = (int64_t)mulhi32(o[0], (uint32_t)num_actions);
+}
+
+}  // namespace
+
+// =================================================================================== C ABI
+struct DcdMg {
+  DcdMgConfig cfg;
+  Params p;
+  int device;
+  uint8_t* rec;
+  uint32_t* seed;
+  Metrics* met;
+  uint32_t* errs;      // [0] bits, [1] first env
+};
+
+namespace dcd {
+thread_local std::string g_last_error;
+int fail(const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  g_last_error = buf;
+  return 1;
+}
+}  // namespace dcd
+
+#define HIP_OK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return dcd::fail("%s: %s", #x, hipGetErrorString(_e)); } while (0)
+#define CHECK_H(h) do { if (!(h)) return dcd::fail("null handle"); } while (0)
+
+static inline int nblk(int n) { return (n + 63) / 64; }
+
+static LevelArgs base_args(DcdMg* h) {
+  LevelArgs a; memset(&a, 0, sizeof a);
+  a.rec = h->rec; a.seed = h->seed; a.met = h->met; a.errs = h->errs; a.n_rows = h->p.B;
+  return a;
+}
+template <int OP> static int launch_level(DcdMg* h, const LevelArgs& a, void* stream) {
+  if (a.n_rows <= 0) return 0;
+  hipLaunchKernelGGL(mg_level_kernel<OP>, dim3(nblk(a.n_rows)), dim3(WAVE), 0, (hipStream_t)stream, h->p, a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+
+extern "C" {
+
+const char* dcd_last_error(void) { return dcd::g_last_error.c_str(); }
+int dcd_abi_version(void) { return DCD_ABI_VERSION; }
+
+int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out) {
+  if (!cfg || !out) return dcd::fail("dcd_mg_create: null argument");
+  if (cfg->num_envs <= 0) return dcd::fail("num_envs must be > 0");
+  if (cfg->size < 3 || cfg->size > DCD_MAX_GRID) return dcd::fail("size %d outside [3,%d]", cfg->size, DCD_MAX_GRID);
+  if (cfg->agent_view_size < 3 || cfg->agent_view_size > DCD_MAX_VIEW || !(cfg->agent_view_size & 1))
+    return dcd::fail("agent_view_size %d must be odd in [3,%d]", cfg->agent_view_size, DCD_MAX_VIEW);
+  if (!cfg->see_through_walls) return dcd::fail("see_through_walls=False (process_vis) is not supported");
+  if (cfg->random_z_dim < 0 || cfg->random_z_dim > 52) return dcd::fail("random_z_dim %d outside [0,52]", cfg->random_z_dim);
+  if (cfg->editor_actions < 0 || cfg->editor_actions > 2) return dcd::fail("editor_actions must be 0..2");
+  if (cfg->n_clutter < 0 || cfg->n_clutter + 2 > 255) return dcd::fail("n_clutter %d out of range", cfg->n_clutter);
+  if (cfg->max_steps <= 0 || cfg->max_steps > 65535 || cfg->max_episode_steps > 65535) return dcd::fail("max_steps out of range");
+  HIP_OK(hipSetDevice(device));
+  DcdMg* h = new DcdMg();
+  h->cfg = *cfg; h->device = device;
+  static const int NEDIT[3] = {2, 3, 4};
+  Params& p = h->p;
+  p.B = cfg->num_envs; p.S = cfg->size; p.V = cfg->agent_view_size; p.max_steps = cfg->max_steps;
+  p.max_episode_steps = cfg->max_episode_steps; p.n_clutter = cfg->n_clutter;
+  p.resample_n_clutter = cfg->resample_n_clutter; p.choose_goal_last = cfg->choose_goal_last;
+  p.random_z_dim = cfg->random_z_dim; p.n_editor_actions = NEDIT[cfg->editor_actions];
+  p.fixed_environment = cfg->fixed_environment; p.goal_noise = cfg->goal_noise; p.engine_seed = cfg->engine_seed;
+  const size_t B = (size_t)p.B;
+  if (hipMalloc(&h->rec, B * REC_BYTES) != hipSuccess || hipMalloc(&h->seed, B * 4) != hipSuccess ||
+      hipMalloc(&h->met, B * sizeof(Metrics)) != hipSuccess || hipMalloc(&h->errs, 8) != hipSuccess) {
+    delete h; return dcd::fail("hipMalloc failed for %zu envs", B);
+  }
+  const uint32_t init[2] = {0u, 0x7fffffffu};
+  HIP_OK(hipMemcpy(h->errs, init, 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(init_records_kernel, dim3((p.B + 255) / 256), dim3(256), 0, 0, p, h->rec, h->seed, h->met,
+                     (long long)cfg->env_index_base);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipDeviceSynchronize());
+  *out = h;
+  return 0;
+}
+
+int dcd_mg_destroy(DcdMg* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipFree(h->rec); (void)hipFree(h->seed); (void)hipFree(h->met); (void)hipFree(h->errs);
+  delete h;
+  return 0;
+}
+
+int dcd_mg_set_seed(DcdMg* h, const int64_t* seeds, void* stream) {
+  CHECK_H(h);
+  hipLaunchKernelGGL(set_seed_kernel, dim3((h->p.B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->rec, h->seed, seeds, h->p.B);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int dcd_mg_poll_errors(DcdMg* h, uint32_t* err_bits, int32_t* first_env, void* stream) {
+  CHECK_H(h);
+  uint32_t host[2];
+  HIP_OK(hipMemcpyAsync(host, h->errs, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+  if (host[0]) {
+    const uint32_t init[2] = {0u, 0x7fffffffu};
+    HIP_OK(hipMemcpyAsync(h->errs, init, 8, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+  }
+  if (err_bits) *err_bits = host[0];
+  if (first_env) *first_env = host[0] ? (int32_t)host[1] : -1;
+  return 0;
+}
+
+int dcd_mg_reset(DcdMg* h, const DcdAdvObs* out, void* stream) {
+  CHECK_H(h);
+  LevelArgs a = base_args(h); if (out) a.adv = *out;
+  return launch_level<OP_RESET>(h, a, stream);
+}
+int dcd_mg_step_adversary(DcdMg* h, const int64_t* loc, const DcdAdvObs* out, uint8_t* done, void* stream) {
+  CHECK_H(h);
+  if (!loc) return dcd::fail("dcd_mg_step_adversary: null loc");
+  LevelArgs a = base_args(h); a.loc = loc; if (out) a.adv = *out; a.adv_done = done;
+  return launch_level<OP_STEP_ADV>(h, a, stream);
+}
+int dcd_mg_reset_agent(DcdMg* h, const DcdStudentObs* out, void* stream) {
+  CHECK_H(h);
+  LevelArgs a = base_args(h); if (out) a.stu = *out;
+  return launch_level<OP_RESET_AGENT>(h, a, stream);
+}
+int dcd_mg_reset_random(DcdMg* h, const DcdStudentObs* out, void* stream) {
+  CHECK_H(h);
+  LevelArgs a = base_args(h); if (out) a.stu = *out;
+  return launch_level<OP_RESET_RANDOM>(h, a, stream);
+}
+int dcd_mg_reset_to_encoding(DcdMg* h, const uint8_t* enc, const int32_t* idx, int32_t n, const DcdStudentObs* out, void* stream) {
+  CHECK_H(h);
+  if (!enc) return dcd::fail("dcd_mg_reset_to_encoding: null enc");
+  if (n < 0 || (!idx && n != h->p.B)) return dcd::fail("dcd_mg_reset_to_encoding: n=%d must equal num_envs=%d when idx is NULL", n, h->p.B);
+  LevelArgs a = base_args(h); a.enc = enc; a.idx = idx; a.n_rows = n; if (out) a.stu = *out;
+  return launch_level<OP_SET_ENCODING>(h, a, stream);
+}
+int dcd_mg_reset_to_actions(DcdMg* h, const int64_t* actions, const int32_t* lens, int32_t max_len, const int32_t* idx, int32_t n,
+                            const DcdStudentObs* out, void* stream) {
+  CHECK_H(h);
+  if (!actions || !lens) return dcd::fail("dcd_mg_reset_to_actions: null actions/lens");
+  if (n < 0 || (!idx && n != h->p.B)) return dcd::fail("dcd_mg_reset_to_actions: n=%d must equal num_envs=%d when idx is NULL", n, h->p.B);
+  LevelArgs a = base_args(h); a.loc = actions; a.lens = lens; a.max_len = max_len; a.idx = idx; a.n_rows = n; if (out) a.stu = *out;
+  return launch_level<OP_REPLAY>(h, a, stream);
+}
+int dcd_mg_mutate_level(DcdMg* h, int32_t num_edits, const DcdStudentObs* out, void* stream) {
+  CHECK_H(h);
+  if (num_edits < 0 || num_edits > 64) return dcd::fail("num_edits %d outside [0,64]", num_edits);
+  LevelArgs a = base_args(h); a.num_edits = num_edits; if (out) a.stu = *out;
+  return launch_level<OP_MUTATE>(h, a, stream);
+}
+
+int dcd_mg_step(DcdMg* h, const int64_t* actions, int32_t flags, const DcdStepOut* out, void* stream) {
+  CHECK_H(h);
+  if (!actions) return dcd::fail("dcd_mg_step: null actions");
+  StepArgs a; memset(&a, 0, sizeof a);
+  a.rec = h->rec; a.seed = h->seed; a.met = h->met; a.errs = h->errs; a.actions = actions; a.flags = flags;
+  if (out) a.out = *out;
+  hipLaunchKernelGGL(mg_step_kernel<false>, dim3(nblk(h->p.B)), dim3(WAVE), 0, (hipStream_t)stream, h->p, a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int dcd_mg_step_random(DcdMg* h, uint32_t action_seed, uint32_t t0, int32_t K, int32_t flags, const DcdStepOut* out,
+                       int64_t* n_episodes, void* stream) {
+  CHECK_H(h);
+  if (K <= 0) return dcd::fail("dcd_mg_step_random: K must be > 0");
+  StepArgs a; memset(&a, 0, sizeof a);
+  a.rec = h->rec; a.seed = h->seed; a.met = h->met; a.errs = h->errs; a.flags = flags;
+  a.K = K; a.action_seed = action_seed; a.t0 = t0; a.env_index_base = h->cfg.env_index_base;
+  a.n_episodes = reinterpret_cast<unsigned long long*>(n_episodes);
+  if (out) a.out = *out;
+  hipLaunchKernelGGL(mg_step_kernel<true>, dim3(nblk(h->p.B)), dim3(WAVE), 0, (hipStream_t)stream, h->p, a);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int dcd_mg_get_encodings(DcdMg* h, uint8_t* out, void* stream) {
+  CHECK_H(h);
+  if (!out) return dcd::fail("dcd_mg_get_encodings: null out");
+  LevelArgs a = base_args(h); a.enc_out = out;
+  return launch_level<OP_READ_ENC>(h, a, stream);
+}
+int dcd_mg_get_metrics(DcdMg* h, int32_t* ncl, int32_t* pas, int32_t* spl, int32_t* dist, void* stream) {
+  CHECK_H(h);
+  hipLaunchKernelGGL(get_metrics_kernel, dim3((h->p.B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->p.B, h->met, ncl, pas, spl, dist);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+int dcd_mg_get_state(DcdMg* h, int32_t* out, void* stream) {
+  CHECK_H(h);
+  if (!out) return dcd::fail("dcd_mg_get_state: null out");
+  hipLaunchKernelGGL(get_state_kernel, dim3((h->p.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->p, h->rec, out);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+int dcd_random_actions(int64_t* actions, int32_t B, int64_t base, uint32_t seed, uint32_t t, int32_t num_actions, void* stream) {
+  if (!actions || B <= 0) return dcd::fail("dcd_random_actions: bad arguments");
+  hipLaunchKernelGGL(random_actions_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, actions, B, (long long)base, seed, t, num_actions);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+"""Tensor-level wrappers of the scan / scoring entry points of the C ABI (include/dcd_hip.h).
+
+Inputs are the [T(+1), B(, 1)] CUDA tensors of a RolloutStorage (time-major, env axis
+contiguous); trailing singleton dims are accepted.  Nothing here synchronises except
+`episode_records`, which must read the record count back.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import DcdHipError, EPISODE_REC_WORDS, check, lib, ptr, stream_ptr
+
+EPISODE_REC = np.dtype([("actor", "<i4"), ("seed", "<i4"), ("start_t", "<i4"), ("num_steps", "<i4"),
+                        ("mean_score", "<f4"), ("max_score", "<f4"), ("reward_sum", "<f4"), ("flags", "<i4")])
+
+
+def _tb(t, rows, B, name, dtype=torch.float32):
+    if t is None:
+        return None
+    if t.dim() == 3 and t.shape[-1] == 1:
+        t = t.squeeze(-1)
+    if t.dim() != 2 or t.shape[0] != rows or t.shape[1] != B:
+        raise DcdHipError(f"{name}: expected shape [{rows},{B}(,1)], got {tuple(t.shape)}")
+    return ptr(t, dtype, rows * B, name)
+
+
+def gae_returns(rewards, value_preds, masks, returns, gamma, gae_lambda):
+    """algos/storage.py:233-256 — writes returns[0:T]."""
+    T, B = rewards.shape[0], rewards.shape[1]
+    check(lib().dcd_gae_returns(_tb(rewards, T, B, "rewards"), _tb(value_preds, T + 1, B, "value_preds"),
+                                _tb(masks, T + 1, B, "masks"), _tb(returns, T + 1, B, "returns"),
+                                C.c_int32(T), C.c_int32(B), C.c_double(gamma), C.c_double(gae_lambda), stream_ptr()))
+    return returns
+
+
+def discounted_returns(rewards, value_preds, masks, returns, gamma):
+    """algos/storage.py:258-276 — writes returns[0:T+1]."""
+    T, B = rewards.shape[0], rewards.shape[1]
+    check(lib().dcd_discounted_returns(_tb(rewards, T, B, "rewards"), _tb(value_preds, T + 1, B, "value_preds"),
+                                       _tb(masks, T + 1, B, "masks"), _tb(returns, T + 1, B, "returns"),
+                                       C.c_int32(T), C.c_int32(B), C.c_double(gamma), stream_ptr()))
+    return returns
+
+
+def batched_value_loss(returns, value_preds, mode=0, power=1, clipped=True, out=None):
+    """algos/storage.py:290-327 — mode 0 abs / 1 signed / 2 positive-only; returns [B,1]."""
+    T, B = returns.shape[0] - 1, returns.shape[1]
+    out = torch.empty((B, 1), dtype=torch.float32, device=returns.device) if out is None else out
+    check(lib().dcd_batched_value_loss(_tb(returns, T + 1, B, "returns"), _tb(value_preds, T + 1, B, "value_preds"),
+                                       ptr(out, torch.float32, B, "out"), C.c_int32(T), C.c_int32(B), C.c_int32(mode),
+                                       C.c_int32(power), C.c_int32(int(clipped)), stream_ptr()))
+    return out
+
+
+class EpisodeScorer:
+    """Owns the record / workspace buffers for dcd_episode_scores on one device."""
+
+    def __init__(self, T, B, device):
+        self.T, self.B, self.device = T, B, device
+        self.max_recs = B * (T + 1)
+        self.recs = torch.zeros((self.max_recs, EPISODE_REC_WORDS), dtype=torch.int32, device=device)
+        self.n_recs = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.workspace = torch.zeros((2 * B + 64,), dtype=torch.int32, device=device)
+
+    def launch(self, returns, value_preds, rewards, masks, cliffhanger_masks, level_seeds, action_log_dist,
+               strategy, gamma):
+        T, B = self.T, self.B
+        A = 0
+        ld = None
+        if action_log_dist is not None:
+            A = action_log_dist.shape[-1]
+            ld = ptr(action_log_dist, torch.float32, T * B * A, "action_log_dist")
+        check(lib().dcd_episode_scores(
+            _tb(returns, T + 1, B, "returns"), _tb(value_preds, T + 1, B, "value_preds"),
+            _tb(rewards, T, B, "rewards"), _tb(masks, T + 1, B, "masks"),
+            _tb(cliffhanger_masks, T + 1, B, "cliffhanger_masks"), _tb(level_seeds, T, B, "level_seeds", torch.int32),
+            ld, C.c_int32(T), C.c_int32(B), C.c_int32(A), C.c_int32(strategy), C.c_double(gamma),
+            ptr(self.recs), C.c_int32(self.max_recs), ptr(self.n_recs), ptr(self.workspace), stream_ptr()))
+
+    def records(self):
+        """Synchronises: returns the records as a numpy structured array (reference order)."""
+        n = int(self.n_recs.item())
+        return self.recs[:n].cpu().numpy().view(EPISODE_REC).reshape(n)
+
+    def grounded(self, n, grounded_values, value_preds, positive_only, dense):
+        """Second pass for grounded_* strategies; grounded_values float32[n] on device."""
+        mean = torch.empty((n,), dtype=torch.float32, device=self.device)
+        mx = torch.empty((n,), dtype=torch.float32, device=self.device)
+        if n:
+            check(lib().dcd_grounded_scores(ptr(self.recs), C.c_int32(n), ptr(grounded_values, torch.float32, n, "grounded"),
+                                            _tb(value_preds, self.T + 1, self.B, "value_preds"), C.c_int32(self.B),
+                                            C.c_int32(int(positive_only)), C.c_int32(int(dense)), ptr(mean), ptr(mx),
+                                            stream_ptr()))
+        return mean, mx
+
+
+def rollout_return_stats(ep_ret, info, mean_out=None, max_out=None, n_out=None):
+    """envs/runners/adversarial_runner.py:257-271 — ep_ret [T,B] fp32, info [T,B] uint8."""
+    T, B = ep_ret.shape
+    d = ep_ret.device
+    mean_out = torch.empty((B, 1), dtype=torch.float32, device=d) if mean_out is None else mean_out
+    max_out = torch.empty((B, 1), dtype=torch.float32, device=d) if max_out is None else max_out
+    n_out = torch.empty((B,), dtype=torch.int32, device=d) if n_out is None else n_out
+    check(lib().dcd_rollout_return_stats(ptr(ep_ret, torch.float32, T * B, "ep_ret"), ptr(info, torch.uint8, T * B, "info"),
+                                         C.c_int32(T), C.c_int32(B), ptr(mean_out, torch.float32, B), ptr(max_out, torch.float32, B),
+                                         ptr(n_out, torch.int32, B), stream_ptr()))
+    return mean_out, max_out, n_out
+
+
+def env_return(agent_mean, agent_max, adv_mean, adv_max, mode=0, out=None):
+    """envs/runners/adversarial_runner.py:637-664 — mode 0 paired, 1 flexible_paired, 2 minimax."""
+    B = agent_max.numel()
+    out = torch.empty_like(agent_max) if out is None else out
+    check(lib().dcd_env_return(ptr(agent_mean, torch.float32, B), ptr(agent_max, torch.float32, B),
+                               ptr(adv_mean, torch.float32, B), ptr(adv_max, torch.float32, B),
+                               ptr(out, torch.float32, B), C.c_int32(B), C.c_int32(mode), stream_ptr()))
+    return out

@@ -257,6 +257,15 @@ int dcd_episode_scores(const float* returns, const float* value_preds, const flo
                        DcdEpisodeRec* recs, int32_t max_recs, int32_t* n_recs,
                        int32_t* workspace, void* stream);
 
+/* grounded_signed/positive_value_loss (level_sampler.py:351-424), second pass once the host
+ * has resolved each record's grounded value g = max(grounded_values[seed_idx], reward_sum)
+ * (:533-538): adv_t = g - V[t, actor] over the record's steps (dense: first step only),
+ * optionally clamp(0); mean_out/max_out[k] for record k (total_steps/new_steps scaling is host
+ * side).  grounded: float[n]. */
+int dcd_grounded_scores(const DcdEpisodeRec* recs, int32_t n, const float* grounded,
+                        const float* value_preds, int32_t B, int32_t positive_only, int32_t dense,
+                        float* mean_out, float* max_out, void* stream);
+
 /* ---- regret ---------------------------------------------------------------- */
 /* _get_rollout_return_stats (adversarial_runner.py:257-271): per env mean and max
  * of the episode returns emitted during a rollout.  ep_ret [T,B] (the per-step

@@ -107,7 +107,8 @@ static int decode_obj(uint8_t t, uint8_t c, uint8_t s, Obj* out) {
       *out = mk(t, c, st); return 0; }
     case DCD_OBJ_GOAL: *out = mk_goal(); return 0;        /* Goal(): colour ignored */
     case DCD_OBJ_LAVA: *out = mk(DCD_OBJ_LAVA, 0, 0); return 0;
-    case DCD_OBJ_AGENT: *out = mk(DCD_OBJ_AGENT, 0, s); return 0; /* Agent(color_idx,state); id forced 0 :271 */
+    case DCD_OBJ_AGENT: if (s > 3) return -1;           /* dir outside DIR_TO_VEC: assert in dir_vec :692 */
+      *out = mk(DCD_OBJ_AGENT, 0, s); return 0;         /* Agent(color_idx,state); id forced 0 :271 */
   }
   return -1;
 }

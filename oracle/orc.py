@@ -83,19 +83,28 @@ def _p(a):
 class OracleMg:
     """Batch of scalar oracle envs with the same call set as the HIP engine."""
 
+    _prefix = "orc_mg_"
+
+    @staticmethod
+    def _library():
+        return lib()
+
+    def _fn(self, name):
+        return getattr(self._library(), self._prefix + name)
+
     def __init__(self, **cfg):
         self.cfg = make_config(**cfg)
         self.B = self.cfg.num_envs
         self.S = self.cfg.size
         self.V = self.cfg.agent_view_size
         self.Z = self.cfg.random_z_dim
-        self.h = C.c_void_p(lib().orc_mg_create(C.byref(self.cfg)))
+        self.h = C.c_void_p(self._fn("create")(C.byref(self.cfg)))
         if not self.h:
             raise ValueError("orc_mg_create rejected the config")
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_mg_destroy(self.h)
+            self._fn("destroy")(self.h)
             self.h = None
 
     # -- buffers
@@ -117,34 +126,34 @@ class OracleMg:
     # -- calls
     def set_seed(self, seeds):
         s = np.ascontiguousarray(seeds, np.int64)
-        lib().orc_mg_set_seed(self.h, _p(s))
+        self._fn("set_seed")(self.h, _p(s))
 
     def poll_errors(self):
         first = C.c_int32(-1)
-        bits = lib().orc_mg_poll_errors(self.h, C.byref(first))
+        bits = self._fn("poll_errors")(self.h, C.byref(first))
         return int(bits), int(first.value)
 
     def reset(self):
         bufs, st = self._adv()
-        lib().orc_mg_reset(self.h, C.byref(st))
+        self._fn("reset")(self.h, C.byref(st))
         return bufs
 
     def step_adversary(self, loc):
         loc = np.ascontiguousarray(loc, np.int64)
         bufs, st = self._adv()
         done = np.zeros((self.B,), np.uint8)
-        lib().orc_mg_step_adversary(self.h, _p(loc), C.byref(st), _p(done))
+        self._fn("step_adversary")(self.h, _p(loc), C.byref(st), _p(done))
         bufs["done"] = done
         return bufs
 
     def reset_agent(self):
         bufs, st = self._student()
-        lib().orc_mg_reset_agent(self.h, C.byref(st))
+        self._fn("reset_agent")(self.h, C.byref(st))
         return bufs
 
     def reset_random(self):
         bufs, st = self._student()
-        lib().orc_mg_reset_random(self.h, C.byref(st))
+        self._fn("reset_random")(self.h, C.byref(st))
         return bufs
 
     def reset_to_encoding(self, enc, idx=None):
@@ -152,7 +161,7 @@ class OracleMg:
         n = enc.shape[0]
         idx_a = None if idx is None else np.ascontiguousarray(idx, np.int32)
         bufs, st = self._student(n)
-        lib().orc_mg_reset_to_encoding(self.h, _p(enc), _p(idx_a), C.c_int32(n), C.byref(st))
+        self._fn("reset_to_encoding")(self.h, _p(enc), _p(idx_a), C.c_int32(n), C.byref(st))
         return bufs
 
     def reset_to_actions(self, actions, lens, idx=None):
@@ -161,13 +170,13 @@ class OracleMg:
         n, max_len = actions.shape
         idx_a = None if idx is None else np.ascontiguousarray(idx, np.int32)
         bufs, st = self._student(n)
-        lib().orc_mg_reset_to_actions(self.h, _p(actions), _p(lens), C.c_int32(max_len), _p(idx_a),
+        self._fn("reset_to_actions")(self.h, _p(actions), _p(lens), C.c_int32(max_len), _p(idx_a),
                                       C.c_int32(n), C.byref(st))
         return bufs
 
     def mutate_level(self, num_edits):
         bufs, st = self._student()
-        lib().orc_mg_mutate_level(self.h, C.c_int32(num_edits), C.byref(st))
+        self._fn("mutate_level")(self.h, C.c_int32(num_edits), C.byref(st))
         return bufs
 
     def step_buffers(self, term_init=None):
@@ -189,25 +198,25 @@ class OracleMg:
     def step(self, actions, flags=0, term_init=None):
         actions = np.ascontiguousarray(actions, np.int64)
         out, st = self.step_buffers(term_init)
-        lib().orc_mg_step(self.h, _p(actions), C.c_int32(flags), C.byref(st))
+        self._fn("step")(self.h, _p(actions), C.c_int32(flags), C.byref(st))
         return out
 
     def step_range(self, actions, flags, st, lo, hi):
-        lib().orc_mg_step_range(self.h, _p(actions), C.c_int32(flags), C.byref(st), C.c_int32(lo), C.c_int32(hi))
+        self._fn("step_range")(self.h, _p(actions), C.c_int32(flags), C.byref(st), C.c_int32(lo), C.c_int32(hi))
 
     def get_encodings(self):
         out = np.zeros((self.B, self.S, self.S, 3), np.uint8)
-        lib().orc_mg_get_encodings(self.h, _p(out))
+        self._fn("get_encodings")(self.h, _p(out))
         return out
 
     def get_metrics(self):
         m = [np.zeros((self.B,), np.int32) for _ in range(4)]
-        lib().orc_mg_get_metrics(self.h, *[_p(a) for a in m])
+        self._fn("get_metrics")(self.h, *[_p(a) for a in m])
         return dict(n_clutter_placed=m[0], passable=m[1], shortest_path_length=m[2], distance_to_goal=m[3])
 
     def get_state(self):
         out = np.zeros((self.B, 16), np.int32)
-        lib().orc_mg_get_state(self.h, _p(out))
+        self._fn("get_state")(self.h, _p(out))
         return out
 
 

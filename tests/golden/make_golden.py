@@ -1,0 +1,353 @@
+"""Generate golden vectors by IMPORTING the reference's own modules (build container only).
+
+Run once from the repo root:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Needs /root/reference (absent on the GPU box: only the committed .npz files travel).
+
+Importable there: algos.{storage,ppo,agent}, level_replay.{level_sampler,
+level_store}, models.multigrid_models — with three in-process shims: numpy aliases removed in
+numpy>=1.24 (np.float/np.bool/np.int/np.NINF), a stub `gym` module (storage.py imports it but
+never uses it; models/walker_models.py needs gym.spaces.MultiDiscrete at import) and a stub
+`lempel_ziv_complexity`.  envs/* is NOT importable (gym, gym_minigrid, baselines missing).
+
+Only data is written: inputs + the reference's outputs.  No reference source is copied.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def install_shims():
+    np.float = float
+    np.bool = bool
+    np.int = int
+    np.NINF = -np.inf
+    gym = types.ModuleType("gym")
+    spaces = types.ModuleType("gym.spaces")
+
+    class MultiDiscrete:  # only referenced by models/walker_models.py at import time
+        pass
+
+    spaces.MultiDiscrete = MultiDiscrete
+    gym.spaces = spaces
+    sys.modules["gym"] = gym
+    sys.modules["gym.spaces"] = spaces
+    lz = types.ModuleType("lempel_ziv_complexity")
+    lz.lempel_ziv_complexity = lambda s: 0
+    sys.modules["lempel_ziv_complexity"] = lz
+    sys.path.insert(0, REF)
+
+
+class Box:
+    def __init__(self, shape, high=255):
+        self.shape = tuple(shape)
+        self.high = np.full(self.shape, high)
+
+
+class Discrete:
+    def __init__(self, n):
+        self.n = n
+        self.shape = ()
+
+    def sample(self):
+        return int(np.random.randint(self.n))
+
+
+def student_spaces():
+    return {"image": Box((3, 5, 5)), "direction": Box((1,), high=3)}, Discrete(7)
+
+
+def synth_rollout(rng, T, B, A=7, p_done=0.12, p_trunc=0.3):
+    """Synthetic buffers shaped like a student RolloutStorage after a rollout."""
+    rewards = (rng.random((T, B, 1)) * (rng.random((T, B, 1)) < 0.05)).astype(np.float32)
+    value_preds = rng.standard_normal((T + 1, B, 1)).astype(np.float32)
+    masks = (rng.random((T + 1, B, 1)) > p_done).astype(np.float32)
+    masks[0] = 1.0
+    masks[T] = 0.0  # runner forces done on the last step
+    bad = np.ones((T + 1, B, 1), np.float32)
+    cliff = np.ones((T + 1, B, 1), np.float32)
+    done_idx = masks == 0
+    bad[done_idx & (rng.random((T + 1, B, 1)) < p_trunc)] = 0.0
+    cliff[T][rng.random((B, 1)) < 0.5] = 0.0
+    bad[T][cliff[T] == 0] = 0.0
+    logits = rng.standard_normal((T, B, A)).astype(np.float32)
+    logits = logits - np.log(np.exp(logits).sum(-1, keepdims=True))  # stored logits are normalised
+    seeds = rng.integers(1, 12, (T, B, 1)).astype(np.int32)
+    # a level seed is constant within an episode
+    for b in range(B):
+        cur = seeds[0, b, 0]
+        for t in range(T):
+            if t > 0 and masks[t, b, 0] == 0:
+                cur = seeds[t, b, 0]
+            seeds[t, b, 0] = cur
+    return dict(rewards=rewards, value_preds=value_preds, masks=masks, bad_masks=bad,
+                cliffhanger_masks=cliff, action_log_dist=logits, level_seeds=seeds)
+
+
+def fill_storage(storage, d):
+    storage.rewards.copy_(torch.from_numpy(d["rewards"]))
+    storage.value_preds.copy_(torch.from_numpy(d["value_preds"]))
+    storage.masks.copy_(torch.from_numpy(d["masks"]))
+    storage.bad_masks.copy_(torch.from_numpy(d["bad_masks"]))
+    storage.cliffhanger_masks.copy_(torch.from_numpy(d["cliffhanger_masks"]))
+    storage.action_log_dist.copy_(torch.from_numpy(d["action_log_dist"]))
+    storage.level_seeds.copy_(torch.from_numpy(d["level_seeds"]))
+
+
+def gen_scans():
+    from algos import RolloutStorage
+    obs_space, act_space = student_spaces()
+    out = {}
+    for name, (T, B, seed) in {"small": (40, 8, 0), "paired": (256, 8, 1)}.items():
+        rng = np.random.default_rng(seed)
+        d = synth_rollout(rng, T, B)
+        st = RolloutStorage(None, T, B, obs_space, act_space, 256, recurrent_arch="lstm")
+        fill_storage(st, d)
+        next_value = torch.from_numpy(rng.standard_normal((B, 1)).astype(np.float32))
+        gamma, lam = 0.995, 0.95
+        st.compute_returns(next_value, True, gamma, lam)
+        gae = st.returns.clone().numpy()
+        vp_after = st.value_preds.clone().numpy()
+        st.returns.zero_()
+        st.compute_returns(next_value, False, gamma, lam)
+        disc = st.returns.clone().numpy()
+        # value losses on the GAE returns
+        st.returns.copy_(torch.from_numpy(gae))
+        vl = {}
+        for key, kw in {"abs": {}, "signed": dict(signed=True), "pos": dict(positive_only=True),
+                        "abs_p2": dict(power=2), "abs_noclip": dict(clipped=False)}.items():
+            vl[key] = st.get_batched_value_loss(**kw).numpy()
+        for k, v in d.items():
+            out[f"{name}_{k}"] = v
+        out[f"{name}_next_value"] = next_value.numpy()
+        out[f"{name}_value_preds_filled"] = vp_after
+        out[f"{name}_gae"] = gae
+        out[f"{name}_disc"] = disc
+        for k, v in vl.items():
+            out[f"{name}_vl_{k}"] = v
+        out[f"{name}_gamma_lambda"] = np.array([gamma, lam])
+    np.savez_compressed(os.path.join(OUT, "scans.npz"), **out)
+    print("scans.npz", len(out))
+
+
+class _Rollouts:
+    """Minimal stand-in exposing the fields LevelSampler reads (level_sampler.py:490-525)."""
+
+    def __init__(self, d, returns):
+        t = torch.from_numpy
+        self.level_seeds = t(d["level_seeds"])
+        self.action_log_dist = t(d["action_log_dist"])
+        self.masks = t(d["masks"])
+        self.bad_masks = t(d["bad_masks"])
+        self.cliffhanger_masks = t(d["cliffhanger_masks"])
+        self.returns = t(returns)
+        self.value_preds = t(d["value_preds"])
+        self.rewards = t(d["rewards"])
+        self.use_popart = False
+
+
+def gen_sampler():
+    from level_replay import LevelSampler
+    obs_space, act_space = student_spaces()
+    scans = np.load(os.path.join(OUT, "scans.npz"))
+    d = {k[len("small_"):]: scans[k] for k in scans.files if k.startswith("small_")}
+    T, B = d["rewards"].shape[:2]
+    out = {}
+    strategies = ["value_l1", "positive_value_loss", "signed_value_loss", "gae", "least_confidence",
+                  "min_margin", "one_step_td_error", "uniform", "grounded_signed_value_loss",
+                  "grounded_positive_value_loss"]
+    for strat in strategies:
+        # (a) fixed seed list ------------------------------------------------------------
+        calls = []
+        s = LevelSampler(list(range(1, 12)), obs_space, act_space, num_actors=B, strategy=strat,
+                         score_transform="rank", temperature=0.1, staleness_coef=0.3, rho=0.5,
+                         replay_prob=0.5, alpha=1.0, gamma=0.995)
+        orig_full = s._partial_update_seed_score
+
+        def log_full(actor_index, seed, score, max_score, num_steps, done=False, _o=orig_full):
+            calls.append((actor_index, seed, float(score), float(max_score), num_steps, int(done)))
+            return _o(actor_index, seed, score, max_score, num_steps, done=done)
+
+        s._partial_update_seed_score = log_full
+        ro = _Rollouts(d, d["gae"])
+        s.update_with_rollouts(ro)
+        out[f"{strat}_calls"] = np.array(calls, dtype=np.float64)
+        out[f"{strat}_seed_scores"] = s.seed_scores.copy()
+        out[f"{strat}_partial_scores"] = s.partial_seed_scores.copy()
+        out[f"{strat}_partial_max"] = s.partial_seed_max_scores.copy()
+        out[f"{strat}_partial_steps"] = s.partial_seed_steps.copy()
+        out[f"{strat}_unseen"] = s.unseen_seed_weights.copy()
+        if s.grounded_values is not None:
+            out[f"{strat}_grounded"] = s.grounded_values.copy()
+        out[f"{strat}_weights"] = s.sample_weights()
+        s._partial_update_seed_score = orig_full
+        s.after_update()
+        out[f"{strat}_seed_scores_after"] = s.seed_scores.copy()
+        out[f"{strat}_weights_after"] = s.sample_weights()
+    # (b) score transforms on a fixed score vector -----------------------------------------
+    rng = np.random.default_rng(5)
+    scores = rng.random(11)
+    stale = rng.integers(0, 30, 11).astype(float)
+    unseen = (rng.random(11) < 0.25).astype(float)
+    out["tf_scores"], out["tf_stale"], out["tf_unseen"] = scores, stale, unseen
+    for tf in ["constant", "eps_greedy", "rank", "power", "softmax", "match", "match_rank"]:
+        for sc in (0.0, 0.3):
+            s = LevelSampler(list(range(1, 12)), obs_space, act_space, num_actors=B, strategy="value_l1",
+                             score_transform=tf, temperature=0.3, staleness_coef=sc,
+                             staleness_transform="power", staleness_temperature=1.0)
+            s.seed_scores = scores.copy()
+            s.seed_staleness = stale.copy()
+            s.unseen_seed_weights = unseen.copy()
+            out[f"tf_{tf}_{sc}"] = s.sample_weights()
+    # (c) robust-PLR style buffer (sample_full_distribution) sequence ---------------------
+    np.random.seed(123)
+    s = LevelSampler([], obs_space, act_space, num_actors=B, strategy="positive_value_loss",
+                     score_transform="rank", temperature=0.1, staleness_coef=0.3, rho=0.5,
+                     replay_prob=0.5, alpha=1.0, sample_full_distribution=True, seed_buffer_size=6,
+                     seed_buffer_priority="replay_support", gamma=0.995)
+    log = []
+    for it in range(4):
+        rng = np.random.default_rng(100 + it)
+        di = synth_rollout(rng, T, B)
+        # staged seeds: new ids per iteration so the buffer overflows and evicts
+        base = 1 + it * 5
+        di["level_seeds"] = (di["level_seeds"] % 5 + base).astype(np.int32)
+        ret = (di["value_preds"] + rng.standard_normal(di["value_preds"].shape).astype(np.float32) * 0.3)
+        seeds_now = sorted(set(int(x) for x in di["level_seeds"].ravel()))
+        solv = [bool(x % 2) for x in seeds_now]
+        s.observe_external_unseen_sample(seeds_now, solv)
+        s.update_with_rollouts(_Rollouts(di, ret))
+        s.after_update()
+        for k, v in di.items():
+            out[f"buf{it}_{k}"] = v
+        out[f"buf{it}_returns"] = ret
+        out[f"buf{it}_observed"] = np.array(seeds_now)
+        out[f"buf{it}_solvable"] = np.array(solv)
+        out[f"buf{it}_seeds"] = s.seeds.copy()
+        out[f"buf{it}_seed_scores"] = s.seed_scores.copy()
+        out[f"buf{it}_staleness"] = s.seed_staleness.copy()
+        out[f"buf{it}_unseen"] = s.unseen_seed_weights.copy()
+        out[f"buf{it}_weights"] = s.sample_weights()
+        out[f"buf{it}_solvable_mass"] = np.array(s.solvable_mass)
+        out[f"buf{it}_filled"] = np.array(s._proportion_filled)
+        log.append(len(s.staging_seed_set))
+    out["buf_staging_sizes"] = np.array(log)
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), **out)
+    print("sampler.npz", len(out))
+
+
+def gen_store():
+    from level_replay import LevelStore
+    out = {}
+    st = LevelStore()
+    a = st.insert(["1 2 3", "4 5 6", "1 2 3"])
+    b = st.insert(["7 8 9", "4 5 6"], parent_seeds=[a[0], a[1]])
+    out["ins_a"], out["ins_b"] = np.array(a), np.array(b)
+    out["parents_len"] = np.array([len(st.seed2parent[k]) for k in sorted(st.seed2parent)])
+    st.reconcile_seeds({1, 3})
+    out["after_reconcile"] = np.array(sorted(st.seed2level))
+    enc = np.arange(27, dtype=np.uint8).reshape(3, 3, 3)
+    st2 = LevelStore(data_info={"numpy": True, "dtype": enc.dtype, "shape": enc.shape})
+    sid = st2.insert([enc.tobytes()])
+    out["bytes_roundtrip"] = st2.get_level(sid[0])
+    np.savez_compressed(os.path.join(OUT, "store.npz"), **out)
+    print("store.npz")
+
+
+def gen_ppo():
+    from algos import RolloutStorage, PPO, ACAgent
+    from models import MultigridNetwork
+    obs_space, act_space = student_spaces()
+    torch.manual_seed(0)
+    net = MultigridNetwork(observation_space=obs_space, action_space=act_space, scalar_fc=5, scalar_dim=4,
+                           recurrent_arch="lstm", recurrent_hidden_size=256)
+    out = {f"w_{k}": v.detach().numpy().copy() for k, v in net.state_dict().items()}
+    out["n_params"] = np.array(sum(p.numel() for p in net.parameters()))
+    T, B = 12, 4
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 11, (T + 1, B, 3, 5, 5)).astype(np.float32) / np.float32(10.0)
+    direction = rng.integers(0, 4, (T + 1, B, 1)).astype(np.float32)
+    masks = (rng.random((T + 1, B, 1)) > 0.15).astype(np.float32)
+    masks[0] = 1
+    masks[T] = 0
+    bad = np.ones_like(masks)
+    bad[(masks == 0) & (rng.random(masks.shape) < 0.6)] = 0
+    rewards = (rng.random((T, B, 1)) * (rng.random((T, B, 1)) < 0.2)).astype(np.float32)
+    algo = PPO(net, clip_param=0.2, ppo_epoch=2, num_mini_batch=1, value_loss_coef=0.5, entropy_coef=0.01,
+               lr=1e-4, eps=1e-5, max_grad_norm=0.5, clip_value_loss=True, log_grad_norm=True)
+    st = RolloutStorage(net, T, B, obs_space, act_space, 256, recurrent_arch="lstm",
+                        use_proper_time_limits=True)
+    agent = ACAgent(algo, st)
+    # roll the policy over the fixed observation tape (actions sampled by the reference)
+    st.obs["image"][0].copy_(torch.from_numpy(img[0]))
+    st.obs["direction"][0].copy_(torch.from_numpy(direction[0]))
+    trunc_img = rng.integers(0, 11, (T + 1, B, 3, 5, 5)).astype(np.float32) / np.float32(10.0)
+    trunc_dir = rng.integers(0, 4, (T + 1, B, 1)).astype(np.float32)
+    st.truncated_obs["image"].copy_(torch.from_numpy(trunc_img))
+    st.truncated_obs["direction"].copy_(torch.from_numpy(trunc_dir))
+    torch.manual_seed(1)
+    vals, acts, dists = [], [], []
+    for t in range(T):
+        with torch.no_grad():
+            v, a, ld, h = agent.act(st.get_obs(t), st.get_recurrent_hidden_state(t), st.masks[t])
+        lp = ld.gather(-1, a)
+        vals.append(v.numpy().copy())
+        acts.append(a.numpy().copy())
+        dists.append(ld.numpy().copy())
+        obs = {"image": torch.from_numpy(img[t + 1]), "direction": torch.from_numpy(direction[t + 1])}
+        agent.insert(obs, h, a, lp, ld, v, torch.from_numpy(rewards[t]), torch.from_numpy(masks[t + 1]),
+                     torch.from_numpy(bad[t + 1]))
+    with torch.no_grad():
+        nv = agent.get_value(st.get_obs(-1), st.get_recurrent_hidden_state(-1), st.masks[-1])
+    st.compute_returns(nv, True, 0.995, 0.95)
+    out.update(img=img, direction=direction, masks=masks, bad_masks=bad, rewards=rewards,
+               trunc_img=trunc_img, trunc_dir=trunc_dir, act_values=np.stack(vals), act_actions=np.stack(acts),
+               act_logdist=np.stack(dists), hidden=st.recurrent_hidden_states.numpy().copy(),
+               next_value=nv.numpy().copy(), truncated_value_preds=st.truncated_value_preds.numpy().copy(),
+               returns=st.returns.numpy().copy(), action_log_probs=st.action_log_probs.numpy().copy())
+    # evaluate_actions over the whole tape (sequence mode of the masked RNN)
+    with torch.no_grad():
+        flat = lambda x: x[:-1].reshape(T * B, *x.shape[2:])
+        ev, elp, eent, _ = net.evaluate_actions(
+            {"image": flat(st.obs["image"]), "direction": flat(st.obs["direction"])},
+            st._split_batched_lstm_recurrent_hidden_states(st.recurrent_hidden_states[0]),
+            flat(st.masks), st.actions.reshape(T * B, 1))
+    out.update(eval_values=ev.numpy().copy(), eval_logp=elp.numpy().copy(), eval_entropy=np.array(eent.item()))
+    torch.manual_seed(2)
+    vl, al, ent, info = agent.update()
+    out.update(ppo_value_loss=np.array(vl), ppo_action_loss=np.array(al), ppo_entropy=np.array(ent),
+               ppo_grad_norms=np.array(info["grad_norms"]))
+    for k, v in net.state_dict().items():
+        out[f"w_after_{k}"] = v.detach().numpy().copy()
+    # discard_grad path: parameters must not move
+    torch.manual_seed(3)
+    st.compute_returns(nv, True, 0.995, 0.95)
+    vl2, al2, ent2, _ = agent.update(discard_grad=True)
+    out.update(ppo2_value_loss=np.array(vl2), ppo2_action_loss=np.array(al2), ppo2_entropy=np.array(ent2))
+    np.savez_compressed(os.path.join(OUT, "ppo.npz"), **out)
+    print("ppo.npz", len(out))
+
+    # teacher net shape facts only (22.5M params: weights not stored)
+    adv_space = {"image": Box((3, 15, 15)), "time_step": Box((1,), high=27), "random_z": Box((50,), high=1)}
+    torch.manual_seed(0)
+    tnet = MultigridNetwork(observation_space=adv_space, action_space=Discrete(169), conv_filters=128,
+                            scalar_fc=10, scalar_dim=28, random_z_dim=50, recurrent_arch="lstm",
+                            recurrent_hidden_size=256)
+    shapes = {k: np.array(v.shape) for k, v in tnet.state_dict().items()}
+    shapes["n_params"] = np.array(sum(p.numel() for p in tnet.parameters()))
+    np.savez_compressed(os.path.join(OUT, "teacher_shapes.npz"), **shapes)
+    print("teacher_shapes.npz")
+
+
+if __name__ == "__main__":
+    install_shims()
+    torch.set_num_threads(1)
+    gen_scans()
+    gen_sampler()
+    gen_store()
+    gen_ppo()

@@ -1,0 +1,113 @@
+"""-m gpu: the HIP MultiGrid engine (through the C ABI) against the CPU oracle, bit-exact.
+
+Every output tensor of every call (u8 and fp32 observations, reward, done, info bits, episode
+stats, masks, truncated obs, teacher obs, random_z) and the full state after each call
+(encodings, agent/level scalars, metrics, rng counters, error words) must be identical on
+identical seeds — integer work and fp32 values produced by identical operations.
+"""
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests import mg_diff
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    # BASELINE config: MultiGrid-GoalLastFewerBlocksAdversarial-v0 (adversarial.py:614-618)
+    (0, dict(n_clutter=25, choose_goal_last=1), False, 130),
+    (1, dict(size=6, n_clutter=7, max_steps=50, max_episode_steps=50, choose_goal_last=1), False, 70),
+    (2, dict(n_clutter=25, choose_goal_last=1, max_episode_steps=50), True, 64),
+    (3, dict(resample_n_clutter=1, n_clutter=60, choose_goal_last=1, editor_actions=1), False, 65),
+    (4, dict(choose_goal_last=0, goal_noise=0.3, n_clutter=50, editor_actions=1), True, 63),
+    (5, dict(size=10, n_clutter=30, max_steps=200, max_episode_steps=200, agent_view_size=7, editor_actions=0), True, 1),
+    (6, dict(n_clutter=25, choose_goal_last=1, agent_view_size=3, fixed_environment=1), False, 200),
+]
+
+
+@pytest.mark.parametrize("seed,kw,exotic,B", CONFIGS)
+def test_engine_matches_oracle(seed, kw, exotic, B):
+    from tests.hip_adapter import HipMg
+    cfg = dict(num_envs=B, engine_seed=seed, env_index_base=1000 * seed)
+    cfg.update(kw)
+    x = orc.OracleMg(**cfg)
+    y = HipMg(**cfg)
+    rng = np.random.default_rng(seed)
+    mg_diff.compare_state(x, y, "after create")
+    episodes = mg_diff.drive(x, y, rng, n_calls=24, steps_per_call=25, exotic=exotic, check_every=5)
+    assert episodes >= 0
+
+
+def test_paired_shape_rollout_bitexact():
+    """4096 envs, teacher builds levels with random actions, 256 student steps with Philox actions:
+    per-step outputs and final state identical to the oracle (BASELINE configs[1] shape)."""
+    from tests.hip_adapter import HipMg
+    import torch
+    import dcd_hip
+    B, T = 4096, 256
+    cfg = dict(num_envs=B, n_clutter=25, choose_goal_last=1, engine_seed=7)
+    x = orc.OracleMg(**cfg)
+    y = HipMg(**cfg)
+    rng = np.random.default_rng(7)
+    x.reset(); y.reset()
+    for k in range(27):
+        loc = rng.integers(0, 169, B)
+        ox, oy = x.step_adversary(loc), y.step_adversary(loc)
+    mg_diff.assert_same(ox, oy, "teacher last obs")
+    mg_diff.assert_same(x.reset_agent(), y.reset_agent(), "reset_agent")
+    tx = ty = None
+    for t in range(T):
+        a = orc.random_actions(B, 0, 1, t, 7)
+        a_dev = dcd_hip.engine.random_actions(B, 0, 1, t, 7, "cuda:0").cpu().numpy()
+        assert np.array_equal(a, a_dev)
+        flags = 2 if t == T - 1 else 0
+        ox, oy = x.step(a, flags, tx), y.step(a, flags, ty)
+        tx, ty = ox["term_obs"], oy["term_obs"]
+        if t % 16 == 0 or t == T - 1:
+            mg_diff.assert_same(ox, oy, f"step {t}")
+    mg_diff.compare_state(x, y, "after rollout")
+
+
+def test_fused_random_steps_match_single_steps():
+    """dcd_mg_step_random(K) == K single dcd_mg_step calls with the same Philox actions."""
+    import torch
+    import dcd_hip
+    B, K = 300, 40
+    cfg = dict(size=15, n_clutter=25, choose_goal_last=1, engine_seed=3)
+    a = dcd_hip.MultiGridEngine(B, **cfg)
+    b = dcd_hip.MultiGridEngine(B, **cfg)
+    for e in (a, b):
+        e.reset_random()
+    n_eps = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    out_a = a.step_buffers()
+    a.step_random(11, 5, K, 0, out_a, n_eps)
+    eps = 0
+    out_b = None
+    for k in range(K):
+        act = dcd_hip.engine.random_actions(B, 0, 11, 5 + k, 7, "cuda:0")
+        out_b = b.step(act, 0, out_b)
+        eps += int((out_b["info"] & 1).sum())
+    assert torch.equal(a.get_encodings(), b.get_encodings())
+    assert torch.equal(a.get_state(), b.get_state())
+    for k in ("reward", "done", "info", "ep_ret", "ep_len"):
+        assert torch.equal(out_a[k], out_b[k]), k
+    assert torch.equal(out_a["obs"]["image_f32"], out_b["obs"]["image_f32"])
+    assert int(n_eps.item()) == eps
+
+
+def test_error_latch():
+    import torch
+    import dcd_hip
+    e = dcd_hip.MultiGridEngine(8, n_clutter=3, choose_goal_last=1)
+    e.reset()
+    bad = torch.full((8,), 169, dtype=torch.int64, device="cuda:0")
+    e.step_adversary(bad)
+    with pytest.raises(ValueError, match="outside the grid"):
+        e.raise_errors()
+    assert e.poll_errors() == (0, -1)
+    e.reset()
+    e.reset_agent()                     # no start position yet
+    with pytest.raises(ValueError, match="empty start position"):
+        e.raise_errors()
+    with pytest.raises(dcd_hip.DcdHipError):
+        e.step(torch.zeros(8, dtype=torch.int64))      # CPU tensor must be refused, not copied

@@ -1,0 +1,158 @@
+"""-m gpu: HIP scans / episode scoring against (a) the reference's golden vectors captured by
+tests/golden/make_golden.py and (b) the CPU oracle on larger seeded inputs.
+
+Tolerances: GAE / discounted returns bit-exact (same fp32 op order, no FMA); means use fp64
+accumulation rounded once, compared to the reference's fp32 torch means with rtol 2e-6;
+max scores exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", ["small", "paired"])
+def test_gae_and_discounted_match_reference_bitexact(name):
+    from dcd_hip import scans
+    g = np.load(os.path.join(G, "scans.npz"))
+    r, v, m = g[f"{name}_rewards"], g[f"{name}_value_preds_filled"], g[f"{name}_masks"]
+    gamma, lam = g[f"{name}_gamma_lambda"]
+    ret = torch.zeros(v.shape, device=DEV)
+    scans.gae_returns(dev(r), dev(v), dev(m), ret, float(gamma), float(lam))
+    assert np.array_equal(bits(ret.cpu().numpy()[:-1]), bits(g[f"{name}_gae"][:-1]))
+    ret.zero_()
+    scans.discounted_returns(dev(r), dev(v), dev(m), ret, float(gamma))
+    assert np.array_equal(bits(ret.cpu().numpy()), bits(g[f"{name}_disc"]))
+
+
+@pytest.mark.parametrize("name", ["small", "paired"])
+def test_batched_value_loss_matches_reference(name):
+    from dcd_hip import scans
+    g = np.load(os.path.join(G, "scans.npz"))
+    R, v = dev(g[f"{name}_gae"]), dev(g[f"{name}_value_preds_filled"])
+    for key, (mode, power, clip) in dict(abs=(0, 1, True), signed=(1, 1, True), pos=(2, 1, True),
+                                         abs_p2=(0, 2, True), abs_noclip=(0, 1, False)).items():
+        out = scans.batched_value_loss(R, v, mode, power, clip).cpu().numpy()
+        np.testing.assert_allclose(out, g[f"{name}_vl_{key}"], rtol=2e-6, atol=1e-7)
+        ref = orc.batched_value_loss(g[f"{name}_gae"][..., 0], g[f"{name}_value_preds_filled"][..., 0], mode, power, clip)
+        assert np.array_equal(bits(out[:, 0]), bits(ref))
+
+
+def _big(T=256, B=4096, seed=0):
+    rng = np.random.default_rng(seed)
+    r = (rng.random((T, B)) * (rng.random((T, B)) < 0.01)).astype(np.float32)
+    v = rng.standard_normal((T + 1, B)).astype(np.float32)
+    m = (rng.random((T + 1, B)) < 0.99).astype(np.float32)
+    m[0] = 1
+    m[T] = 0
+    return rng, r, v, m
+
+
+def test_gae_full_size_matches_oracle_bitexact():
+    from dcd_hip import scans
+    _, r, v, m = _big()
+    ret = torch.zeros((257, 4096), device=DEV)
+    scans.gae_returns(dev(r), dev(v), dev(m), ret, 0.995, 0.95)
+    assert np.array_equal(bits(ret.cpu().numpy()[:-1]), bits(orc.gae_returns(r, v, m, 0.995, 0.95)[:-1]))
+    scans.discounted_returns(dev(r), dev(v), dev(m), ret, 0.995)
+    assert np.array_equal(bits(ret.cpu().numpy()), bits(orc.discounted_returns(r, v, m, 0.995)))
+    # odd sizes: T not a multiple of the unroll, B not a multiple of 64
+    r2, v2, m2 = r[:37, :77].copy(), v[:38, :77].copy(), m[:38, :77].copy()
+    ret2 = torch.zeros((38, 77), device=DEV)
+    scans.gae_returns(dev(r2), dev(v2), dev(m2), ret2, 0.999, 0.9)
+    assert np.array_equal(bits(ret2.cpu().numpy()[:-1]), bits(orc.gae_returns(r2, v2, m2, 0.999, 0.9)[:-1]))
+
+
+STRATS = dict(value_l1=0, positive_value_loss=1, signed_value_loss=2, least_confidence=4, min_margin=5,
+              one_step_td_error=6, uniform=7)
+
+
+@pytest.mark.parametrize("strategy", sorted(STRATS))
+def test_episode_scores_match_reference_calls(strategy):
+    """Records vs the (actor, seed, score, max, steps, done) sequence the reference's LevelSampler
+    passed to _partial_update_seed_score on the same buffers (tests/golden/sampler.npz)."""
+    from dcd_hip import scans
+    g, s = np.load(os.path.join(G, "scans.npz")), np.load(os.path.join(G, "sampler.npz"))
+    d = {k[len("small_"):]: g[k] for k in g.files if k.startswith("small_")}
+    T, B = d["rewards"].shape[:2]
+    sc = scans.EpisodeScorer(T, B, DEV)
+    sc.launch(dev(d["gae"]), dev(d["value_preds"]), dev(d["rewards"]), dev(d["masks"]), dev(d["cliffhanger_masks"]),
+              dev(d["level_seeds"]), dev(d["action_log_dist"]), STRATS[strategy], 0.995)
+    recs = sc.records()
+    keep = recs[(recs["flags"] & 2) == 0]
+    calls = s[f"{strategy}_calls"]
+    assert len(keep) == len(calls)
+    assert np.array_equal(keep["actor"], calls[:, 0]) and np.array_equal(keep["seed"], calls[:, 1])
+    assert np.array_equal(keep["num_steps"], calls[:, 4]) and np.array_equal(keep["flags"] & 1, calls[:, 5])
+    np.testing.assert_allclose(keep["mean_score"], calls[:, 2], rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(keep["max_score"], calls[:, 3], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("strategy", [0, 1, 2, 4, 5, 6, 7, 8])
+def test_episode_scores_full_size_match_oracle(strategy):
+    from dcd_hip import scans
+    T, B, A = 256, 4096, 7
+    rng, r, v, m = _big(T, B, seed=3)
+    m = (rng.random((T + 1, B)) < 0.97).astype(np.float32)
+    m[0] = 1
+    m[T] = 0
+    R = (v + 0.3 * rng.standard_normal(v.shape)).astype(np.float32)
+    cliff = np.ones_like(m)
+    cliff[T][rng.random(B) < 0.5] = 0
+    seeds = rng.integers(1, 5000, (T, B)).astype(np.int32)
+    ld = rng.standard_normal((T, B, A)).astype(np.float32)
+    sc = scans.EpisodeScorer(T, B, DEV)
+    sc.launch(dev(R), dev(v), dev(r), dev(m), dev(cliff), dev(seeds), dev(ld), strategy, 0.995)
+    recs = sc.records()
+    ref = orc.episode_scores(R, v, r, m, cliff, seeds, ld, strategy, 0.995)
+    assert len(recs) == len(ref)
+    for k in ("actor", "seed", "start_t", "num_steps", "flags"):
+        assert np.array_equal(recs[k], ref[k]), k
+    if strategy in (4, 5):          # expf/logf differ between device and host libm
+        np.testing.assert_allclose(recs["mean_score"], ref["mean_score"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(recs["max_score"], ref["max_score"], rtol=1e-5, atol=1e-6)
+    else:
+        assert np.array_equal(bits(recs["mean_score"]), bits(ref["mean_score"]))
+        assert np.array_equal(bits(recs["max_score"]), bits(ref["max_score"]))
+    assert np.array_equal(bits(recs["reward_sum"]), bits(ref["reward_sum"]))
+    # grounded second pass
+    n = len(recs)
+    gv = rng.standard_normal(n).astype(np.float32)
+    for pos, dense in ((0, 0), (1, 0), (1, 1)):
+        mean, mx = sc.grounded(n, dev(gv), dev(v), pos, dense)
+        rm, rx = orc.grounded_scores(ref, gv, v, pos, dense)
+        assert np.array_equal(bits(mean.cpu().numpy()), bits(rm)) and np.array_equal(bits(mx.cpu().numpy()), bits(rx))
+
+
+def test_return_stats_and_regret_match_oracle():
+    from dcd_hip import scans
+    rng = np.random.default_rng(9)
+    T, B = 256, 1000
+    info = ((rng.random((T, B)) < 0.02) * 1 + (rng.random((T, B)) < 0.1) * 2).astype(np.uint8)
+    ep = (rng.random((T, B)) * (rng.random((T, B)) < 0.5)).astype(np.float32)
+    mean, mx, n = scans.rollout_return_stats(dev(ep), dev(info))
+    rm, rx, rn = orc.rollout_return_stats(ep, info)
+    assert np.array_equal(bits(mean.cpu().numpy()[:, 0]), bits(rm)) and np.array_equal(bits(mx.cpu().numpy()[:, 0]), bits(rx))
+    assert np.array_equal(n.cpu().numpy(), rn)
+    a = [rng.random(B).astype(np.float32) for _ in range(4)]
+    for mode in (0, 1, 2):
+        out = scans.env_return(*[dev(x) for x in a], mode=mode).cpu().numpy()
+        assert np.array_equal(bits(out), bits(orc.env_return(*a, mode=mode)))
