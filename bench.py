@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the MultiGrid PAIRED rollout-and-regret hot path on MI355X.
+
+Contract (see task statement): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line
+on rank 0.  One bench "step" = one PAIRED pass of the hot path over B = 4096 envs on each GPU
+(BASELINE.json configs[1], env MultiGrid-GoalLastFewerBlocksAdversarial-v0):
+
+    teacher   reset + 27 × step_adversary          (random teacher: Philox actions, fp32 CHW obs out)
+    student×2 reset_agent + 256 × { action array → dcd_mg_step → obs/reward/masks/episode stats
+              written straight into the time-major rollout buffers }   (protagonist, antagonist)
+    scans     GAE returns ×2, per-episode positive-value-loss scoring ×2, per-env return stats ×2,
+              PAIRED regret max(antag_max − protag_mean, 0)
+
+i.e. every hand-written kernel of the path, with synthetic inputs: Philox4x32-10 uniform actions
+(an int64 action array in HBM per step, exactly what a policy would hand over), value predictions
+~ N(0,1).  The policy/value networks (PyTorch) are NOT in this number; `--mode rollout` adds them.
+Inputs are resident in HBM before the timed region; the whole pass is captured once into a HIP
+graph (no host round trip per env step) and replayed K times.
+
+env-steps counted per pass and GPU: 2·B·T student steps + B·27 teacher steps.
+N > 1: one process per GPU (torch.distributed / RCCL), envs sharded by rank with no data-path
+collective in the rollout; per pass the ranks all-gather their per-episode score records and
+per-env regrets (the LevelSampler hand-off).  value = global env-steps / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dcd-isaac_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# algorithmic bytes per env-step of dcd_mg_step as benchmarked (fp32 CHW obs variant):
+# action 8 + dyn state r/w 2*16 + 5x5x3 window read 75 + <=2 cell writes 6 + obs 300+4 (f32 image + dir)
+# + reward 4 + done 1  = 430
+STEP_ALGO_BYTES = 430
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--num-steps", type=int, default=256, help="student rollout length T")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-work budget of the cpu_baseline leg")
+    ap.add_argument("--sweep", action="store_true", help="also time dcd_mg_step alone at large B (roofline sweep)")
+    return ap.parse_args()
+
+
+class PairedPass:
+    """All device buffers + the launch sequence of one PAIRED hot-path pass."""
+
+    N_CLUTTER = 25
+
+    def __init__(self, B, T, device, rank):
+        import dcd_hip
+        from dcd_hip import scans
+        self.dcd_hip, self.scans = dcd_hip, scans
+        self.B, self.T, self.dev, self.rank = B, T, device, rank
+        self.base = rank * B
+        self.eng = dcd_hip.MultiGridEngine(B, device=device, size=15, agent_view_size=5, max_steps=250,
+                                           max_episode_steps=250, n_clutter=self.N_CLUTTER, choose_goal_last=1,
+                                           random_z_dim=50, engine_seed=0, env_index_base=self.base)
+        self.Tadv = self.N_CLUTTER + 2
+        z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=device)
+        # teacher rollout buffers (obs of step k+1 written by step k; adversarial_runner.py:481,515)
+        self.adv = dict(image=z(self.Tadv + 1, B, 3, 15, 15), time_step=z(self.Tadv + 1, B, 1),
+                        random_z=z(self.Tadv + 1, B, 50), done=z(self.Tadv, B, dt=torch.uint8),
+                        loc=z(self.Tadv, B, dt=torch.int64))
+        gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.agents = []
+        for _ in range(2):
+            a = dict(image=z(T + 1, B, 3, 5, 5), direction=z(T + 1, B, 1), trunc_image=z(T + 1, B, 3, 5, 5),
+                     trunc_dir=z(T + 1, B, 1), rewards=z(T, B), masks=torch.ones(T + 1, B, device=device),
+                     bad_masks=torch.ones(T + 1, B, device=device), cliff=torch.ones(T + 1, B, device=device),
+                     value_preds=torch.randn(T + 1, B, generator=gen).to(device), returns=z(T + 1, B),
+                     actions=z(T, B, dt=torch.int64), level_seeds=z(T, B, dt=torch.int32),
+                     done=z(T, B, dt=torch.uint8), info=z(T, B, dt=torch.uint8), ep_ret=z(T, B),
+                     ep_len=z(T, B, dt=torch.int32), mean_ret=z(B, 1), max_ret=z(B, 1), n_eps=z(B, dt=torch.int32),
+                     scorer=scans.EpisodeScorer(T, B, device))
+            a["level_seeds"][:] = (torch.arange(B, device=device, dtype=torch.int32) + self.base)[None, :]
+            self.agents.append(a)
+        self.regret = z(B, 1)
+        self.pass_idx = 0
+
+    def run(self):
+        """Issues every launch of one pass on the current stream; no host synchronisation."""
+        eng, T, B, adv, ra = self.eng, self.T, self.B, self.adv, self.dcd_hip.engine.random_actions
+        eng.reset(dict(image_f32=adv["image"][0], time_step=adv["time_step"][0], random_z=adv["random_z"][0]))
+        ra(B, self.base, 2, 0, eng.n_adv_actions, self.dev, out=adv["loc"], T=self.Tadv)      # synthetic teacher actions
+        for k in range(self.Tadv):
+            eng.step_adversary(adv["loc"][k], dict(image_f32=adv["image"][k + 1], time_step=adv["time_step"][k + 1],
+                                                   random_z=adv["random_z"][k + 1], done=adv["done"][k]))
+        for ai, a in enumerate(self.agents):
+            eng.reset_agent(dict(image_f32=a["image"][0], dir_f32=a["direction"][0]))
+            ra(B, self.base, 3 + ai, 0, 7, self.dev, out=a["actions"], T=T)                    # synthetic student actions
+            for t in range(T):
+                eng.step(a["actions"][t], self.dcd_hip.STEP_LAST if t == T - 1 else 0, dict(
+                    obs=dict(image_f32=a["image"][t + 1], dir_f32=a["direction"][t + 1]),
+                    term_obs=dict(image_f32=a["trunc_image"][t + 1], dir_f32=a["trunc_dir"][t + 1]),
+                    reward=a["rewards"][t], done=a["done"][t], info=a["info"][t], ep_ret=a["ep_ret"][t],
+                    ep_len=a["ep_len"][t], masks=a["masks"][t + 1], bad_masks=a["bad_masks"][t + 1],
+                    cliffhanger_masks=a["cliff"][t + 1]))
+            self.scans.gae_returns(a["rewards"], a["value_preds"], a["masks"], a["returns"], 0.995, 0.95)
+            a["scorer"].launch(a["returns"], a["value_preds"], a["rewards"], a["masks"], a["cliff"], a["level_seeds"],
+                               None, self.dcd_hip.SCORE_STRATEGY["positive_value_loss"], 0.995)
+            self.scans.rollout_return_stats(a["ep_ret"], a["info"], a["mean_ret"], a["max_ret"], a["n_eps"])
+        p, q = self.agents
+        self.scans.env_return(p["mean_ret"], p["max_ret"], q["mean_ret"], q["max_ret"], mode=0, out=self.regret)
+
+    def steps_per_pass(self):
+        return 2 * self.B * self.T + self.B * self.Tadv
+
+
+def gather_scores(ps, world):
+    """LevelSampler hand-off: all ranks' per-episode records + regrets (RCCL all-gather)."""
+    import torch.distributed as dist
+    n_local = torch.stack([a["scorer"].n_recs for a in ps.agents]).view(-1)          # [2] int32 on device
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    mx = int(torch.stack(counts).max().item())
+    outs = []
+    for a in ps.agents:
+        buf = torch.empty((world, mx, 8), dtype=torch.int32, device=ps.dev)
+        dist.all_gather_into_tensor(buf.view(world * mx, 8), a["scorer"].recs[:mx].contiguous())
+        outs.append(buf)
+    reg = torch.empty((world, ps.B), dtype=torch.float32, device=ps.dev)
+    dist.all_gather_into_tensor(reg.view(-1), ps.regret.view(-1))
+    return counts, outs, reg
+
+
+def cpu_baseline(B, T, budget_s):
+    """The CPU oracle (scalar C port of the reference's env path) on this box's host cores, on a bounded
+    sample of the same workload: teacher-built levels + 256-step student rollouts with the same Philox
+    actions, full StepOut written each step.  A reported baseline, not the target."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import orc
+    cores = len(os.sched_getaffinity(0))
+    nt = max(1, min(16, cores))
+    m = orc.OracleMg(num_envs=B, n_clutter=25, choose_goal_last=1)
+    m.reset()
+    for k in range(27):
+        m.step_adversary(orc.random_actions(B, 0, 2, k, 169))
+    m.reset_agent()
+    out, st = m.step_buffers()
+    rolls, steps, t_used = 0, 0, 0.0
+    with ThreadPoolExecutor(nt) as ex:
+        while t_used * nt < budget_s and rolls < 8:
+            t0 = time.perf_counter()
+            list(ex.map(lambda i: m.rollout_range(st, i * B // nt, (i + 1) * B // nt, T, 3, rolls * T), range(nt)))
+            t_used += time.perf_counter() - t0
+            steps += B * T
+            rolls += 1
+            m.reset_agent()
+    return dict(value=steps / t_used, unit="env-steps/s", cores=nt, kind="port",
+                sample=f"{rolls} student rollouts of {B} envs x {T} steps (oracle C port, {nt} threads, "
+                       f"{t_used:.1f}s wall, full StepOut incl. fp32 obs)")
+
+
+def step_kernel_profile(ps, n=256):
+    """Average duration of the dominant kernel (mg_step_kernel) from HIP events attached to each
+    dispatch, on torch's current stream, over one eager student rollout of the benchmark workload."""
+    a = ps.agents[0]
+    ps.eng.reset_agent(dict(image_f32=a["image"][0], dir_f32=a["direction"][0]))
+    ps.eng.profile_begin(n)
+    for t in range(n):
+        tt = t % ps.T
+        ps.eng.step(a["actions"][tt], 0, dict(
+            obs=dict(image_f32=a["image"][tt + 1], dir_f32=a["direction"][tt + 1]),
+            term_obs=dict(image_f32=a["trunc_image"][tt + 1], dir_f32=a["trunc_dir"][tt + 1]),
+            reward=a["rewards"][tt], done=a["done"][tt], info=a["info"][tt], ep_ret=a["ep_ret"][tt],
+            ep_len=a["ep_len"][tt], masks=a["masks"][tt + 1], bad_masks=a["bad_masks"][tt + 1],
+            cliffhanger_masks=a["cliff"][tt + 1]))
+    launches, ms = ps.eng.profile_end()
+    return ms / max(launches, 1) * 1e-3          # seconds per launch
+
+
+def sweep_large_b(device, sizes=(65536, 1048576), iters=30):
+    """dcd_mg_step alone at large B (HBM-bound regime), same outputs as the benchmark step."""
+    import dcd_hip
+    res = []
+    for B in sizes:
+        eng = dcd_hip.MultiGridEngine(B, device=device, n_clutter=25, choose_goal_last=1)
+        eng.reset_random()
+        act = dcd_hip.engine.random_actions(B, 0, 3, 0, 7, device)
+        out = eng.step_buffers(u8=False)
+        for _ in range(3):
+            eng.step(act, 0, out)
+        eng.profile_begin(iters)
+        for _ in range(iters):
+            eng.step(act, 0, out)
+        n, ms = eng.profile_end()
+        dt = ms / n * 1e-3
+        res.append(dict(envs=B, us_per_launch=dt * 1e6, env_steps_per_s=B / dt,
+                        achieved_GBs=B * STEP_ALGO_BYTES / dt / 1e9, frac=B * STEP_ALGO_BYTES / dt / 1e9 / HBM_PEAK_GBS))
+        eng.close()
+        del out
+        torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU mode")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    B, T = args.envs, args.num_steps
+    ps = PairedPass(B, T, device, rank)
+    stream = torch.cuda.Stream(device)
+    graph = None
+    with torch.cuda.stream(stream):
+        ps.run()                                    # eager once (also warms allocations)
+        stream.synchronize()
+        ps.eng.raise_errors()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                ps.run()
+
+        def one_pass():
+            if graph is not None:
+                graph.replay()
+            else:
+                ps.run()
+            if world > 1:
+                gather_scores(ps, world)
+
+        for _ in range(args.warmup):
+            one_pass()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_pass()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        ps.eng.raise_errors()
+        n_recs = [int(a["scorer"].n_recs.item()) for a in ps.agents]
+        episodes = [int(a["n_eps"].sum().item()) for a in ps.agents]
+        kernel_s = step_kernel_profile(ps) if rank == 0 else None
+        sweep = sweep_large_b(device) if (args.sweep and rank == 0) else None
+
+    if rank == 0:
+        total_steps = ps.steps_per_pass() * world * args.steps
+        algo = B * STEP_ALGO_BYTES
+        achieved = algo / kernel_s / 1e9
+        line = {
+            "metric": "env-steps/sec (whole node), MultiGrid PAIRED 4096 envs/GPU",
+            "value": total_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "MultiGrid-GoalLastFewerBlocksAdversarial-v0 PAIRED hot-path pass: teacher 27 steps + "
+                                   "2 student rollouts x 256 steps + GAE + positive_value_loss episode scoring + regret; "
+                                   "Philox uniform actions, N(0,1) value predictions, no policy nets",
+                       "envs_per_gpu": B, "num_steps": T, "teacher_steps": ps.Tadv, "grid": "15x15", "view": "5x5",
+                       "hip_graph": graph is not None, "parallelism": f"env-sharded x{world}",
+                       "env_steps_per_pass_per_gpu": ps.steps_per_pass(),
+                       "episode_records_last_pass": n_recs, "episodes_last_pass": episodes},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "mg_step_kernel<false>",
+                         "algorithmic_bytes_per_launch": algo, "avg_launch_us": kernel_s * 1e6,
+                         "note": "B=4096 moves 1.76 MB per launch: latency-bound, see DESIGN.md; --sweep adds large-B"},
+        }
+        if sweep is not None:
+            line["roofline_large_b"] = sweep
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(B, T, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,7 @@
 //        240 agent_x (0xFF none) 241 agent_y 242 agent_dir 243 carrying (cell code, 0 none)
 //        244 step_count u16   246 elapsed_steps u16 (TimeLimit)   248 ep_len u16 (VecMonitor)
 //        250 env.done  251 spare   252 ep_ret f32 (VecMonitor)
+//      (held in registers while a lane owns the env: Env::load_dyn / store_dyn)
 //
 // Packed cell codes (55 values; decode(encode(code)) is the identity, and set_encoding's
 // normalisations — Goal() colour, door state>=3, agent id — are built in):
@@ -32,6 +33,14 @@
 #else
 #define DCD_HD static inline
 #define DCD_HDM inline
+#endif
+// On the device an env record is ALWAYS in LDS while a lane works on it; typing the pointers as
+// address_space(3) makes every access a ds_read/ds_write (generic "flat" accesses also count on
+// vmcnt and would wait for outstanding global stores).  Host builds (tests/hostsim) use plain pointers.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DCD_REC __attribute__((address_space(3)))
+#else
+#define DCD_REC
 #endif
 
 namespace dcd {
@@ -110,41 +119,61 @@ DCD_HD bool dec3(uint8_t t, uint8_t col, uint8_t s, uint8_t* code) {
 }
 
 // ---------------------------------------------------------------- env view over the record bytes
+// The 16-byte dynamic state is held in REGISTERS while a lane works on its env (one 16-byte load at
+// make_env, one 16-byte store at store_dyn); only grid cells and the side column are touched in
+// LDS.  has_pos <=> ax != NOPOS.
 struct Env {
-  uint8_t* r;          // 256-byte record (LDS or host memory), row pitch 16
+  DCD_REC uint8_t* r;  // 256-byte record (LDS on device, host memory in tests/hostsim), row pitch 16
   uint32_t seed;       // Philox key word 0 (per-env seed)
   uint32_t err;        // DCD_ERR_* bits raised by this call
   // write-back bookkeeping for the hot step: cells changed (<=2) or everything
-  uint16_t doff[2];
+  int doff0, doff1;    // scalars, not an array: a dynamically indexed member would pin the whole Env to scratch
   int nd;
   bool full_dirty;
+  // dynamic state (bytes 240..255 of the record)
+  int ax, ay, adir, carrying, done;
+  int step_count, elapsed, ep_len;
+  float ep_ret;
 
-  DCD_HDM uint8_t& cell(int x, int y) { return r[y * ROW + x]; }
-  DCD_HDM uint8_t& sb(int k) { return r[k * ROW + 15]; }
+  DCD_HDM DCD_REC uint8_t& cell(int x, int y) { return r[y * ROW + x]; }
+  DCD_HDM DCD_REC uint8_t& sb(int k) { return r[k * ROW + 15]; }
   DCD_HDM void set_cell(int x, int y, uint8_t c) {
     r[y * ROW + x] = c;
-    if (!full_dirty) { if (nd < 2) doff[nd++] = (uint16_t)(y * ROW + x); else full_dirty = true; }
+    if (!full_dirty) {
+      const int o = y * ROW + x;
+      if (nd == 0) { doff0 = o; nd = 1; } else if (nd == 1) { doff1 = o; nd = 2; } else full_dirty = true;
+    }
   }
-  DCD_HDM uint16_t get16(int o) const { return (uint16_t)(r[o] | (r[o + 1] << 8)); }
-  DCD_HDM void put16(int o, uint32_t v) { r[o] = (uint8_t)v; r[o + 1] = (uint8_t)(v >> 8); }
-  // dyn accessors
-  DCD_HDM uint8_t& ax() { return r[DYN + 0]; }
-  DCD_HDM uint8_t& ay() { return r[DYN + 1]; }
-  DCD_HDM uint8_t& adir() { return r[DYN + 2]; }
-  DCD_HDM uint8_t& carrying() { return r[DYN + 3]; }
-  DCD_HDM uint8_t& done() { return r[DYN + 10]; }
-  DCD_HDM bool has_pos() { return r[DYN + 0] != NOPOS; }
-  DCD_HDM float ep_ret() const { uint32_t u = r[DYN + 12] | (r[DYN + 13] << 8) | (r[DYN + 14] << 16) | ((uint32_t)r[DYN + 15] << 24);
-                                float f; __builtin_memcpy(&f, &u, 4); return f; }
-  DCD_HDM void set_ep_ret(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4);
-                                    r[DYN + 12] = (uint8_t)u; r[DYN + 13] = (uint8_t)(u >> 8); r[DYN + 14] = (uint8_t)(u >> 16); r[DYN + 15] = (uint8_t)(u >> 24); }
+  DCD_HDM bool has_pos() const { return ax != NOPOS; }
+  DCD_HDM void pack_dyn(uint32_t w[4]) const {
+    w[0] = (uint32_t)ax | ((uint32_t)ay << 8) | ((uint32_t)adir << 16) | ((uint32_t)carrying << 24);
+    w[1] = (uint32_t)step_count | ((uint32_t)elapsed << 16);
+    w[2] = (uint32_t)ep_len | ((uint32_t)done << 16);
+    __builtin_memcpy(&w[3], &ep_ret, 4);
+  }
+  DCD_HDM void load_dyn() {
+    uint32_t w[4];
+    const DCD_REC uint32_t* q = reinterpret_cast<const DCD_REC uint32_t*>(r + DYN);   // 16-byte aligned
+    w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
+    ax = w[0] & 255; ay = (w[0] >> 8) & 255; adir = (w[0] >> 16) & 255; carrying = w[0] >> 24;
+    step_count = w[1] & 0xFFFF; elapsed = w[1] >> 16;
+    ep_len = w[2] & 0xFFFF; done = (w[2] >> 16) & 255;
+    __builtin_memcpy(&ep_ret, &w[3], 4);
+  }
+  DCD_HDM void store_dyn() {
+    uint32_t w[4]; pack_dyn(w);
+    DCD_REC uint32_t* q = reinterpret_cast<DCD_REC uint32_t*>(r + DYN);
+    q[0] = w[0]; q[1] = w[1]; q[2] = w[2]; q[3] = w[3];
+  }
   // rng draw counter lives in SB8..11
   DCD_HDM uint32_t ctr() { return sb(8) | (sb(9) << 8) | (sb(10) << 16) | ((uint32_t)sb(11) << 24); }
   DCD_HDM void set_ctr(uint32_t v) { sb(8) = (uint8_t)v; sb(9) = (uint8_t)(v >> 8); sb(10) = (uint8_t)(v >> 16); sb(11) = (uint8_t)(v >> 24); full_dirty = true; }
 };
 
-DCD_HD Env make_env(uint8_t* rec, uint32_t seed) {
-  Env e; e.r = rec; e.seed = seed; e.err = 0; e.nd = 0; e.full_dirty = false; e.doff[0] = e.doff[1] = 0; return e;
+DCD_HD Env make_env(DCD_REC uint8_t* rec, uint32_t seed) {
+  Env e; e.r = rec; e.seed = seed; e.err = 0; e.nd = 0; e.full_dirty = false; e.doff0 = e.doff1 = 0;
+  e.load_dyn();
+  return e;
 }
 
 DCD_HD uint32_t rand_u32(Env& e, const Params& p) {
@@ -190,7 +219,7 @@ DCD_HD void gen_grid(Env& e, const Params& p) {
 // drawn as the k-th such cell in row-major order.  code==C_NONE: position only (place_one_agent).
 DCD_HD bool place_uniform(Env& e, const Params& p, uint8_t code, int* px, int* py) {
   const int S = p.S;
-  const int ex = e.has_pos() ? e.ax() : -1, ey = e.ay();
+  const int ex = e.has_pos() ? e.ax : -1, ey = e.ay;
   int n = 0;
   for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x)
     n += (e.cell(x, y) == C_NONE && !(x == ex && y == ey)) ? 1 : 0;
@@ -205,25 +234,25 @@ DCD_HD bool place_uniform(Env& e, const Params& p, uint8_t code, int* px, int* p
 
 // place_agent_at_pos (multigrid.py:668-681); rand_dir=True means dir := 0 (:670-672)
 DCD_HD void place_agent_at_pos(Env& e, int x, int y, bool rand_dir) {
-  e.ax() = (uint8_t)x; e.ay() = (uint8_t)y;
-  if (rand_dir) e.adir() = 0;
-  e.set_cell(x, y, C_AGENT0 + e.adir());
+  e.ax = x; e.ay = y;
+  if (rand_dir) e.adir = 0;
+  e.set_cell(x, y, (uint8_t)(C_AGENT0 + e.adir));
 }
 // place_one_agent with top=None (multigrid.py:651-666)
 DCD_HD bool place_one_agent(Env& e, const Params& p, bool rand_dir, int* px, int* py) {
-  e.ax() = NOPOS;
+  e.ax = NOPOS;
   if (!place_uniform(e, p, C_NONE, px, py)) return false;
   place_agent_at_pos(e, *px, *py, rand_dir);
   return true;
 }
 DCD_HD void reset_agent_status(Env& e) {                                  // adversarial.py:231-236
-  e.ax() = NOPOS; e.adir() = e.sb(2); e.done() = 0; e.carrying() = C_NONE;
+  e.ax = NOPOS; e.adir = e.sb(2); e.done = 0; e.carrying = C_NONE;
 }
 // AdversarialEnv.reset_agent (adversarial.py:238-269); TimeLimit counter is the caller's job
 DCD_HD void reset_agent(Env& e) {
-  if (e.has_pos()) e.set_cell(e.ax(), e.ay(), C_NONE);
+  if (e.has_pos()) e.set_cell(e.ax, e.ay, C_NONE);
   reset_agent_status(e);
-  e.put16(DYN + 4, 0);                                                      // step_count
+  e.step_count = 0;                                                      // step_count
   if (e.sb(0) == NOPOS) { e.err |= DCD_ERR_NO_START_POS; return; }
   place_agent_at_pos(e, e.sb(0), e.sb(1), false);
 }
@@ -272,7 +301,7 @@ DCD_HD void compute_metrics(Env& e, const Params& p, Metrics& m) {
 
 // AdversarialEnv.reset (adversarial.py:194-229): z == nullptr still consumes the draws
 DCD_HD void env_reset(Env& e, const Params& p, Metrics& m, float* z) {
-  e.put16(DYN + 4, 0); e.sb(6) = 0;
+  e.step_count = 0; e.sb(6) = 0;
   if (p.resample_n_clutter) e.sb(5) &= (uint8_t)~1u;
   e.sb(2) = (uint8_t)randint(e, p, 4);
   reset_agent_status(e);
@@ -350,7 +379,7 @@ DCD_HD void env_set_encoding(Env& e, const Params& p, Metrics& m, const uint8_t*
 // reset_random (adversarial.py:541-581)
 DCD_HD void env_reset_random(Env& e, const Params& p, Metrics& m) {
   if (p.fixed_environment) e.set_ctr(0);
-  e.put16(DYN + 4, 0); e.sb(6) = 0;
+  e.step_count = 0; e.sb(6) = 0;
   reset_agent_status(e);
   e.sb(0) = NOPOS; e.sb(3) = NOPOS;
   reset_metrics(m, p);
@@ -430,56 +459,61 @@ DCD_HD void env_mutate_level(Env& e, const Params& p, Metrics& m, int num_edits)
     if (pass == 0) { e.set_cell(x, y, C_GOAL); e.sb(3) = (uint8_t)x; e.sb(4) = (uint8_t)y; }
     else { place_agent_at_pos(e, x, y, true); e.sb(0) = (uint8_t)x; e.sb(1) = (uint8_t)y; }
   }
-  e.put16(DYN + 4, 0); e.sb(6) = 0;
+  e.step_count = 0; e.sb(6) = 0;
   reset_metrics(m, p);
   compute_metrics(e, p, m);
   reset_agent(e);
   e.full_dirty = true;
 }
 
-// agent_is_done (multigrid.py:821-838)
-DCD_HD void agent_is_done(Env& e, const Params& p) {
-  e.set_cell(e.ax(), e.ay(), C_NONE);
-  e.done() = 1;
+// agent_is_done (multigrid.py:821-838).  The respawned agent is wiped by the auto reset_agent of
+// the same step (parallel_wrappers.py:30-35); its position is observable ONLY through
+// info['truncated_obs'] when the time limit fires on the same step.  When it is
+// not (need_pos == false) the draw is still consumed — the counter stays in lock-step with the
+// oracle — but the 225-cell scan is skipped and the agent is left unplaced.
+DCD_HD void agent_is_done(Env& e, const Params& p, bool need_pos) {
+  e.set_cell(e.ax, e.ay, C_NONE);
+  e.done = 1;
   int px, py;
-  if (e.carrying() != C_NONE) { place_uniform(e, p, e.carrying(), &px, &py); e.carrying() = C_NONE; }
-  place_one_agent(e, p, true, &px, &py);
+  if (e.carrying != C_NONE) { place_uniform(e, p, (uint8_t)e.carrying, &px, &py); e.carrying = C_NONE; }
+  if (need_pos) place_one_agent(e, p, true, &px, &py);
+  else { e.ax = NOPOS; e.adir = 0; e.set_ctr(e.ctr() + 1); }
 }
 
 // step_one_agent (multigrid.py:866-941); returns the fp64 reward rounded to fp32 (obs_wrappers.py:179)
-DCD_HD double step_one_agent(Env& e, const Params& p, int action, int step_count) {
-  const int d = e.adir();
-  const int fx = e.ax() + ((d == 0) - (d == 2)), fy = e.ay() + ((d == 1) - (d == 3));   // DIR_TO_VEC
+DCD_HD double step_one_agent(Env& e, const Params& p, int action, int step_count, bool need_respawn_pos) {
+  const int d = e.adir;
+  const int fx = e.ax + ((d == 0) - (d == 2)), fy = e.ay + ((d == 1) - (d == 3));   // DIR_TO_VEC
   const bool ok = fx >= 0 && fx < p.S && fy >= 0 && fy < p.S;
   if (!ok) e.err |= DCD_ERR_OUT_OF_GRID;
   const uint8_t fwd = ok ? e.cell(fx, fy) : C_WALL_GREY;
   double reward = 0.0;
   switch (action) {
-    case DCD_ACT_LEFT: e.adir() = (uint8_t)((d + 3) & 3); e.set_cell(e.ax(), e.ay(), C_AGENT0 + e.adir()); break;
-    case DCD_ACT_RIGHT: e.adir() = (uint8_t)((d + 1) & 3); e.set_cell(e.ax(), e.ay(), C_AGENT0 + e.adir()); break;
+    case DCD_ACT_LEFT: e.adir = (d + 3) & 3; e.set_cell(e.ax, e.ay, (uint8_t)(C_AGENT0 + e.adir)); break;
+    case DCD_ACT_RIGHT: e.adir = (d + 1) & 3; e.set_cell(e.ax, e.ay, (uint8_t)(C_AGENT0 + e.adir)); break;
     case DCD_ACT_FORWARD:
       if (!ok) break;
       if (fwd == C_GOAL) {
-        agent_is_done(e, p);
+        agent_is_done(e, p, need_respawn_pos);
         reward = 1.0 - 0.9 * ((double)step_count / (double)p.max_steps);   // MiniGridEnv._reward
       } else if (fwd == C_LAVA) {
-        agent_is_done(e, p);
+        agent_is_done(e, p, need_respawn_pos);
       } else if (fwd == C_NONE || can_overlap(fwd)) {                       // move_agent :840-853
-        e.set_cell(e.ax(), e.ay(), C_NONE);
-        e.ax() = (uint8_t)fx; e.ay() = (uint8_t)fy;
-        e.set_cell(fx, fy, C_AGENT0 + d);
+        e.set_cell(e.ax, e.ay, C_NONE);
+        e.ax = fx; e.ay = fy;
+        e.set_cell(fx, fy, (uint8_t)(C_AGENT0 + d));
       }
       break;
     case DCD_ACT_PICKUP:
-      if (ok && can_pickup(fwd) && e.carrying() == C_NONE) { e.carrying() = fwd; e.set_cell(fx, fy, C_NONE); }
+      if (ok && can_pickup(fwd) && e.carrying == C_NONE) { e.carrying = fwd; e.set_cell(fx, fy, C_NONE); }
       break;
     case DCD_ACT_DROP:
-      if (ok && fwd == C_NONE && e.carrying() != C_NONE) { e.set_cell(fx, fy, e.carrying()); e.carrying() = C_NONE; }
+      if (ok && fwd == C_NONE && e.carrying != C_NONE) { e.set_cell(fx, fy, (uint8_t)e.carrying); e.carrying = C_NONE; }
       break;
     case DCD_ACT_TOGGLE:
       if (ok && is_door(fwd)) {                                             // Door.toggle multigrid.py:113-123
         const int dd = fwd - C_DOOR0, col = dd / 3, st = dd % 3;
-        if (st == 2) { if (e.carrying() == C_KEY0 + col) e.set_cell(fx, fy, C_DOOR0 + col * 3); }
+        if (st == 2) { if (e.carrying == C_KEY0 + col) e.set_cell(fx, fy, C_DOOR0 + col * 3); }
         else e.set_cell(fx, fy, C_DOOR0 + col * 3 + (st == 0 ? 1 : 0));
       } else if (ok && fwd >= C_BOX0 && fwd < C_GOAL) {
         e.set_cell(fx, fy, C_NONE);                                          // Box.toggle: contents (None)
@@ -496,18 +530,18 @@ DCD_HD double step_one_agent(Env& e, const Params& p, int action, int step_count
 // out: V*V*3 bytes indexed [vx][vy][c].  Out-of-grid cells render as Wall() (grey) (:330-334);
 // the agent's own cell shows the carried object or empty (:1009-1013); other Agent objects seen in
 // the view have their dir rotated with the view (rotate_left :308-314).
-DCD_HD void render_view(Env& e, const Params& p, uint8_t* out) {
-  const int V = p.V, S = p.S, d = e.adir();
+DCD_HD void render_view(Env& e, const Params& p, DCD_REC uint8_t* out) {
+  const int V = p.V, S = p.S, d = e.adir;
   const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3), rx = -fy, ry = fx;
-  const int ax = e.ax(), ay = e.ay(), h = V / 2;
+  const int ax = e.ax, ay = e.ay, h = V / 2;
   for (int vx = 0; vx < V; ++vx) for (int vy = 0; vy < V; ++vy) {
     const int wx = ax + fx * (V - 1 - vy) + rx * (vx - h), wy = ay + fy * (V - 1 - vy) + ry * (vx - h);
     uint8_t c;
-    if (vx == h && vy == V - 1) c = e.carrying();
+    if (vx == h && vy == V - 1) c = (uint8_t)e.carrying;
     else if (wx < 0 || wx >= S || wy < 0 || wy >= S) c = C_WALL_GREY;
     else { c = e.cell(wx, wy); if (is_agent(c)) c = (uint8_t)(C_AGENT0 + (((c - C_AGENT0) - (d + 1)) & 3)); }
     const uint32_t t = enc3(c);
-    uint8_t* o = out + (vx * V + vy) * 3;
+    DCD_REC uint8_t* o = out + (vx * V + vy) * 3;
     o[0] = (uint8_t)t; o[1] = (uint8_t)(t >> 8); o[2] = (uint8_t)(t >> 16);
   }
 }
@@ -517,35 +551,37 @@ struct StepResult { float reward; uint8_t done, info; float ep_ret; int32_t ep_l
 // worker.step_env ∘ TimeLimit.step ∘ MultiGridEnv.step ∘ VecMonitor.step_wait [∘ runner last-step rule].
 // term (V*V*3 bytes + 1 dir byte at term[V*V*3]) receives the pre-reset obs when have_term.
 DCD_HD StepResult env_step(Env& e, const Params& p, Metrics& m, bool& metrics_dirty, int64_t action64,
-                           int flags, uint8_t* term) {
+                           int flags, DCD_REC uint8_t* term) {
   StepResult r;
-  const int step_count = e.get16(DYN + 4) + 1;                             // multigrid.py:948
-  e.put16(DYN + 4, step_count);
+  const int step_count = e.step_count + 1;                                 // multigrid.py:948
+  e.step_count = step_count;
   const int action = (action64 < 0 || action64 > 6) ? 7 : (int)action64;
-  const double reward = step_one_agent(e, p, action, step_count);
-  bool done = e.done() >= 1;                                               // competitive, n_agents == 1
+  // will TimeLimit attach truncated_obs this step?  (then the respawn position is observable)
+  const bool will_term = p.max_episode_steps > 0 && e.elapsed + 1 >= p.max_episode_steps;
+  const double reward = step_one_agent(e, p, action, step_count, will_term);
+  bool done = e.done >= 1;                                               // competitive, n_agents == 1
   if (step_count >= p.max_steps) done = true;                             // :972-973
   uint8_t info = 0; bool have_term = false;
   if (p.max_episode_steps > 0) {                                           // time_limit.py:24-33
-    const int el = e.get16(DYN + 6) + 1;
-    e.put16(DYN + 6, el);
+    const int el = e.elapsed + 1;
+    e.elapsed = el;
     if (el >= p.max_episode_steps) {
       info |= DCD_INFO_TRUNC_KEY; if (!done) info |= DCD_INFO_TRUNCATED;
       have_term = true; done = true;
     }
   }
-  if (have_term) { render_view(e, p, term); term[p.V * p.V * 3] = e.adir(); }
+  if (have_term) { render_view(e, p, term); term[p.V * p.V * 3] = (uint8_t)e.adir; }
   if (done) {                                                              // parallel_wrappers.py:27-37
     if (flags & DCD_STEP_RESET_RANDOM) { env_reset_random(e, p, m); metrics_dirty = true; }
     reset_agent(e);
-    e.put16(DYN + 6, 0);                                                   // time_limit.py:39-49
+    e.elapsed = 0;                                                         // time_limit.py:39-49
   }
   // VecMonitor.step_wait (vec_monitor.py:60-85): eprets(f32) += rews(f64) is an fp64 add rounded to f32
-  float epr = (float)((double)e.ep_ret() + reward);
-  int epl = e.get16(DYN + 8) + 1;
+  float epr = (float)((double)e.ep_ret + reward);
+  int epl = e.ep_len + 1;
   r.ep_ret = 0.f; r.ep_len = 0;
   if (done) { info |= DCD_INFO_EPISODE; r.ep_ret = epr; r.ep_len = epl; epr = 0.f; epl = 0; }
-  e.set_ep_ret(epr); e.put16(DYN + 8, epl);
+  e.ep_ret = epr; e.ep_len = epl;
   if (flags & DCD_STEP_LAST) {                                             // adversarial_runner.py:521-530
     if (!done) info |= DCD_INFO_CLIFFHANGER | DCD_INFO_TRUNC_KEY | DCD_INFO_TRUNCATED;
     done = true;

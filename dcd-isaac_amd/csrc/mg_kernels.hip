@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <vector>
+#include <hip/hip_ext.h>
 #include "mg_env.h"
 #include "dcd_internal.h"
 
@@ -30,54 +32,104 @@ constexpr int MAX_OP = 152;        // staged u8 obs per env: V*V*3 + dir, padded
 
 __device__ __forceinline__ int obs_pitch(int V) { return (V * V * 3 + 1 + 3) & ~3; }
 
+typedef DCD_REC uint8_t lds_u8;      // address_space(3) in the device pass, plain in the host pass
+__device__ __forceinline__ lds_u8* as_lds(uint8_t* p) { return (lds_u8*)p; }
+
 // ---- wave-cooperative record staging ------------------------------------------------------
-// rows: env index of each of the wave's `n` rows comes from env_of[row] (LDS int array)
-__device__ __forceinline__ void stage_in(uint8_t* lds, const uint8_t* __restrict__ rec, const int* env_of,
-                                         int n, int lane) {
-#pragma unroll 4
-  for (int k = 0; k < 16; ++k) {
-    const int q = k * WAVE + lane, row = q >> 4, c = q & 15;
-    if (row < n) {
-      const uint4 v = *reinterpret_cast<const uint4*>(rec + (size_t)env_of[row] * REC_BYTES + c * 16);
-      *reinterpret_cast<uint4*>(lds + row * LP + c * 16) = v;
-    }
-  }
-}
+// rows: env index of each of the workgroup's `n` rows comes from env_of[row] (LDS int array).
+// ROWS*16 16-byte chunks over 64 lanes: loads are issued first (all in flight), LDS writes after.
 __device__ __forceinline__ void stage_out(const uint8_t* lds, uint8_t* __restrict__ rec, const int* env_of,
                                           int n, int lane) {
-#pragma unroll 4
-  for (int k = 0; k < 16; ++k) {
-    const int q = k * WAVE + lane, row = q >> 4, c = q & 15;
-    if (row < n) {
-      const uint4 v = *reinterpret_cast<const uint4*>(lds + row * LP + c * 16);
-      *reinterpret_cast<uint4*>(rec + (size_t)env_of[row] * REC_BYTES + c * 16) = v;
-    }
+  for (int q = lane; q < n * 16; q += WAVE) {
+    const int row = q >> 4, c = q & 15;
+    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * LP + c * 16);
+    *reinterpret_cast<uint4*>(rec + (size_t)env_of[row] * REC_BYTES + c * 16) = v;
   }
 }
 
-// ---- coalesced emission of staged student observations --------------------------------------
-// sobs: [n][OP] bytes ([vx][vy][c] then dir).  Output row of staged row r is out_row0 + r.
-__device__ __forceinline__ void emit_student(const uint8_t* sobs, const float* lut, const DcdStudentObs& o,
-                                             size_t out_row0, int n, int V, int lane, const uint8_t* valid) {
+// k/10.0 evaluated in fp64 and rounded once to fp32 (VecPreprocessImageWrapper._preprocess,
+// obs_wrappers.py:90-91,96) for every byte value enc3 can produce (type<=10, colour<=5, state<=3).
+__constant__ float kDiv10[16] = {(float)(0 / 10.0), (float)(1 / 10.0), (float)(2 / 10.0), (float)(3 / 10.0),
+                                 (float)(4 / 10.0), (float)(5 / 10.0), (float)(6 / 10.0), (float)(7 / 10.0),
+                                 (float)(8 / 10.0), (float)(9 / 10.0), (float)(10 / 10.0), (float)(11 / 10.0),
+                                 (float)(12 / 10.0), (float)(13 / 10.0), (float)(14 / 10.0), (float)(15 / 10.0)};
+// LUTs shared by the emission code, indexed by packed cell code: the 3 encoding bytes and their /10 floats
+struct Luts { uint32_t enc[64]; float f[3][64]; float div10[16]; };
+__device__ __forceinline__ void init_luts(Luts& l, int lane) {
+  const uint32_t t = lane < C_END ? enc3((uint8_t)lane) : 0u;
+  l.enc[lane] = t;
+  l.f[0][lane] = kDiv10[t & 15]; l.f[1][lane] = kDiv10[(t >> 8) & 15]; l.f[2][lane] = kDiv10[(t >> 16) & 15];
+  if (lane < 16) l.div10[lane] = kDiv10[lane];
+}
+
+// ---- fused render + emit of the student observation, cooperative over the workgroup -----------
+// One (env row, view cell) pair per lane-iteration: world cell through the closed-form map of
+// multigrid.py:1080-1093, packed code from the LDS record, channel values from the code LUTs, stored
+// as fp32 CHW (/10) and/or u8 [vx][vy][c].  Consecutive lanes hit consecutive view cells of the same
+// env, so each channel's store is a run of contiguous floats.  Semantics == dcd::render_view.
+template <int V>
+__device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
+                                            int n, int S, int lane) {
+  constexpr int VV = V * V, H = V / 2;
+  if (o.image_u8 || o.image_f32) {
+#pragma unroll 4
+    for (int q = lane; q < n * VV; q += WAVE) {
+      const int row = q / VV, ci = q - row * VV, vx = ci / V, vy = ci - vx * V;
+      const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + row * LP + DYN);
+      const int ax = dyn & 255, ay = (dyn >> 8) & 255, d = (dyn >> 16) & 255, carry = dyn >> 24;
+      const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
+      const int wx = ax + fx * (V - 1 - vy) - fy * (vx - H), wy = ay + fy * (V - 1 - vy) + fx * (vx - H);
+      const bool own = (vx == H && vy == V - 1), oob = (wx < 0 || wx >= S || wy < 0 || wy >= S);
+      int c = lds[row * LP + ((own || oob) ? DYN + 3 : wy * ROW + wx)];      // own cell -> carrying byte
+      if (oob && !own) c = C_WALL_GREY;
+      else if (!own && c >= C_AGENT0 && c < C_DOOR0) c = C_AGENT0 + (((c - C_AGENT0) - (d + 1)) & 3);
+      (void)carry;
+      const bool none = (ax == NOPOS);                                   // no agent placed yet: zero obs
+      const size_t r = out_row0 + row;
+      if (o.image_f32) {
+        float* f = o.image_f32 + r * (3 * VV) + ci;
+        const float f0 = lut.f[0][c], f1 = lut.f[1][c], f2 = lut.f[2][c];
+        f[0] = none ? 0.f : f0; f[VV] = none ? 0.f : f1; f[2 * VV] = none ? 0.f : f2;
+      }
+      if (o.image_u8) {
+        const uint32_t t = none ? 0u : lut.enc[c];
+        uint8_t* u = o.image_u8 + (r * VV + ci) * 3;
+        u[0] = (uint8_t)t; u[1] = (uint8_t)(t >> 8); u[2] = (uint8_t)(t >> 16);
+      }
+    }
+  }
+  if (lane < n) {
+    const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + lane * LP + DYN);
+    const int d = ((dyn & 255) == NOPOS) ? 0 : ((dyn >> 16) & 255);
+    if (o.dir_u8) o.dir_u8[out_row0 + lane] = (uint8_t)d;
+    if (o.dir_f32) o.dir_f32[out_row0 + lane] = (float)d;
+  }
+}
+__device__ __forceinline__ void render_emit_v(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
+                                              int n, int S, int V, int lane) {
+  if (V == 5) render_emit<5>(lds, lut, o, out_row0, n, S, lane);
+  else if (V == 7) render_emit<7>(lds, lut, o, out_row0, n, S, lane);
+  else render_emit<3>(lds, lut, o, out_row0, n, S, lane);
+}
+
+// ---- emission of per-lane staged observations (terminal obs: rare) ---------------------------
+// sobs: [n][OP] bytes ([vx][vy][c] then dir); rows with valid[row]==0 are left untouched.
+__device__ __forceinline__ void emit_staged(const uint8_t* sobs, const Luts& lut, const DcdStudentObs& o,
+                                            size_t out_row0, int n, int V, int lane, const uint8_t* valid) {
   const int VV = V * V, E = VV * 3, OP = obs_pitch(V);
   if (o.image_u8) for (int f = lane; f < n * E; f += WAVE) {
     const int row = f / E, el = f - row * E;
-    if (!valid || valid[row]) o.image_u8[out_row0 * E + f] = sobs[row * OP + el];
+    if (valid[row]) o.image_u8[out_row0 * E + f] = sobs[row * OP + el];
   }
   if (o.image_f32) for (int f = lane; f < n * E; f += WAVE) {
     const int row = f / E, el = f - row * E, c = el / VV, rem = el - c * VV;
-    if (!valid || valid[row]) o.image_f32[out_row0 * E + f] = lut[sobs[row * OP + rem * 3 + c]];
+    if (valid[row]) o.image_f32[out_row0 * E + f] = lut.div10[sobs[row * OP + rem * 3 + c] & 15];
   }
-  if (lane < n && (!valid || valid[lane])) {
+  if (lane < n && valid[lane]) {
     const uint8_t d = sobs[lane * OP + E];
     if (o.dir_u8) o.dir_u8[out_row0 + lane] = d;
     if (o.dir_f32) o.dir_f32[out_row0 + lane] = (float)d;
   }
-}
-
-__device__ __forceinline__ void init_lut(float* lut, int lane) {
-  // VecPreprocessImageWrapper: image/10.0 in fp64, then .float() (obs_wrappers.py:90-91,96)
-  for (int k = lane; k < 256; k += WAVE) lut[k] = (float)((double)k / 10.0);
 }
 
 __device__ __forceinline__ void raise(uint32_t* errs, uint32_t bits, int env) {
@@ -91,57 +143,87 @@ struct StepArgs {
   DcdStepOut out;
   // fused random-action mode (dcd_mg_step_random)
   int K; uint32_t action_seed, t0; int64_t env_index_base; unsigned long long* n_episodes;
+  unsigned long long* stamps;   // diagnostic build only (-DDCD_STAMPS): [grid][8] s_memtime per phase
 };
 
-template <bool RANDOM>
+#ifdef DCD_STAMPS
+#define STAMP(i) do { if (lane == 0 && a.stamps) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
+// EPB = envs per workgroup (one 64-lane wave each).  Lanes [0,EPB) run the per-env logic; ALL lanes
+// share staging and the fused render/emit.  Small batches use EPB=16 so that B=4096 still spreads
+// over all 256 CUs; large batches use EPB=64 (every lane busy in the logic phase).
+template <bool RANDOM, int EPB>
 __global__ void __launch_bounds__(WAVE) mg_step_kernel(Params p, StepArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVE * LP];
-  __shared__ __attribute__((aligned(16))) uint8_t sobs[WAVE * MAX_OP];
-  __shared__ __attribute__((aligned(16))) uint8_t sterm[WAVE * MAX_OP];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[EPB * LP];
+  __shared__ __attribute__((aligned(16))) uint8_t sterm[EPB * MAX_OP];
   __shared__ uint8_t term_valid[WAVE];
   __shared__ int env_of[WAVE];
-  __shared__ float lut[256];
-  const int lane = threadIdx.x, env0 = blockIdx.x * WAVE;
-  const int n = min(WAVE, p.B - env0), env = env0 + lane;
-  const int OP = obs_pitch(p.V), E = p.V * p.V * 3;
+  __shared__ Luts lut;
+  const int lane = threadIdx.x, env0 = blockIdx.x * EPB;
+  const int n = min(EPB, p.B - env0), env = env0 + lane;
+  const int OP = obs_pitch(p.V);
+  STAMP(0);
   env_of[lane] = env;
-  init_lut(lut, lane);
+  term_valid[lane] = 0;
+  // issue every independent global load up front: records, action, seed (one HBM round trip in all)
+  uint4 buf[EPB / 4];
+#pragma unroll
+  for (int i = 0; i < EPB / 4; ++i) {
+    const int q = i * WAVE + lane, row = q >> 4, c = q & 15;
+    buf[i] = make_uint4(0, 0, 0, 0);
+    if (row < n) buf[i] = *reinterpret_cast<const uint4*>(a.rec + (size_t)(env0 + row) * REC_BYTES + c * 16);
+  }
+  int64_t act0 = 0; uint32_t seed = 0;
+  if (lane < n) { seed = a.seed[env]; if (!RANDOM) act0 = a.actions[env]; }
+  init_luts(lut, lane);
+  STAMP(1);
+#pragma unroll
+  for (int i = 0; i < EPB / 4; ++i) {
+    const int q = i * WAVE + lane, row = q >> 4, c = q & 15;
+    if (row < n) *reinterpret_cast<uint4*>(lds + row * LP + c * 16) = buf[i];
+  }
   __syncthreads();
-  stage_in(lds, a.rec, env_of, n, lane);
-  __syncthreads();
+  STAMP(2);
 
-  StepResult r; r.reward = 0.f; r.done = 0; r.info = 0; r.ep_ret = 0.f; r.ep_len = 0; r.have_term = false;
   unsigned long long episodes = 0;
   if (lane < n) {
-    Env e = make_env(lds + lane * LP, a.seed[env]);
+    Env e = make_env(as_lds(lds + lane * LP), seed);
     Metrics m = {0, 0, 0, 0}; bool mdirty = false;
     if (a.flags & DCD_STEP_RESET_RANDOM) m = a.met[env];
+    StepResult r;
     const int K = RANDOM ? a.K : 1;
     for (int k = 0; k < K; ++k) {
-      int64_t act;
+      int64_t act = act0;
       if (RANDOM) {
         uint32_t o[4];
         philox4x32_10(a.t0 + k, 0, 0, 0, a.action_seed, (uint32_t)(a.env_index_base + env), o);
         act = (int64_t)mulhi32(o[0], 7u);
-      } else act = a.actions[env];
+      }
       const int fl = (RANDOM && k != K - 1) ? (a.flags & ~DCD_STEP_LAST) : a.flags;
-      r = env_step(e, p, m, mdirty, act, fl, sterm + lane * OP);
+      r = env_step(e, p, m, mdirty, act, fl, as_lds(sterm + lane * OP));
       if (RANDOM) episodes += (r.info & DCD_INFO_EPISODE) ? 1 : 0;
     }
-    // post-reset observation
-    if (e.has_pos()) { render_view(e, p, sobs + lane * OP); sobs[lane * OP + E] = e.adir(); }
-    else for (int i = 0; i <= E; ++i) sobs[lane * OP + i] = 0;
     term_valid[lane] = r.have_term ? 1 : 0;
-    // write-back: dyn always; cells by dirty list or whole record
+    STAMP(3);
+    e.store_dyn();                                   // LDS copy feeds the cooperative render below
+    // write-back: dyn always; cells by dirty list or whole record (LDS reads first, then the stores)
     uint8_t* g = a.rec + (size_t)env * REC_BYTES;
-    *reinterpret_cast<uint4*>(g + DYN) = *reinterpret_cast<const uint4*>(e.r + DYN);
+    uint32_t w[4]; e.pack_dyn(w);
     if (e.full_dirty) {
-#pragma unroll 5
-      for (int y = 0; y < 15; ++y) *reinterpret_cast<uint4*>(g + y * ROW) = *reinterpret_cast<const uint4*>(e.r + y * ROW);
+      uint4 rows[15];
+#pragma unroll
+      for (int y = 0; y < 15; ++y) rows[y] = *reinterpret_cast<const uint4*>(lds + lane * LP + y * ROW);
+#pragma unroll
+      for (int y = 0; y < 15; ++y) *reinterpret_cast<uint4*>(g + y * ROW) = rows[y];
     } else {
-      if (e.nd > 0) g[e.doff[0]] = e.r[e.doff[0]];
-      if (e.nd > 1) g[e.doff[1]] = e.r[e.doff[1]];
+      const uint8_t c0 = lds[lane * LP + e.doff0], c1 = lds[lane * LP + e.doff1];
+      if (e.nd > 0) g[e.doff0] = c0;
+      if (e.nd > 1) g[e.doff1] = c1;
     }
+    *reinterpret_cast<uint4*>(g + DYN) = make_uint4(w[0], w[1], w[2], w[3]);
     if (mdirty) a.met[env] = m;
     raise(a.errs, e.err, env);
     const DcdStepOut& o = a.out;
@@ -153,11 +235,13 @@ __global__ void __launch_bounds__(WAVE) mg_step_kernel(Params p, StepArgs a) {
     if (o.masks) o.masks[env] = r.done ? 0.f : 1.f;                                      // runner :566-573
     if (o.bad_masks) o.bad_masks[env] = (r.info & DCD_INFO_TRUNC_KEY) ? 0.f : 1.f;
     if (o.cliffhanger_masks) o.cliffhanger_masks[env] = (r.info & DCD_INFO_CLIFFHANGER) ? 0.f : 1.f;
-  } else term_valid[lane] = 0;
+  }
   __syncthreads();
-  emit_student(sobs, lut, a.out.obs, (size_t)env0, n, p.V, lane, nullptr);
-  const unsigned long long any_term = __ballot(term_valid[lane] != 0);
-  if (any_term) emit_student(sterm, lut, a.out.term_obs, (size_t)env0, n, p.V, lane, term_valid);
+  STAMP(4);
+  render_emit_v(lds, lut, a.out.obs, (size_t)env0, n, p.S, p.V, lane);     // post-auto-reset observation
+  STAMP(5);
+  if (__ballot(term_valid[lane] != 0)) emit_staged(sterm, lut, a.out.term_obs, (size_t)env0, n, p.V, lane, term_valid);
+  STAMP(6);
   if (RANDOM && a.n_episodes) {
     for (int off = 32; off > 0; off >>= 1) episodes += __shfl_down(episodes, off);
     if (lane == 0 && episodes) atomicAdd(a.n_episodes, episodes);
@@ -183,48 +267,60 @@ struct LevelArgs {
 template <int OP>
 __global__ void __launch_bounds__(WAVE) mg_level_kernel(Params p, LevelArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[WAVE * LP];
-  __shared__ __attribute__((aligned(16))) uint8_t sobs[WAVE * MAX_OP];
   __shared__ int env_of[WAVE];
-  __shared__ float lut[256];
+  __shared__ Luts lut;
   const int lane = threadIdx.x, row0 = blockIdx.x * WAVE;
   const int n = min(WAVE, a.n_rows - row0), row = row0 + lane;
-  const int S = p.S, OPI = obs_pitch(p.V), E = p.V * p.V * 3;
+  const int S = p.S;
   int env = -1;
   if (lane < n) env = a.idx ? a.idx[row] : row;
   env_of[lane] = env;
-  init_lut(lut, lane);
+  init_luts(lut, lane);
   __syncthreads();
-  stage_in(lds, a.rec, env_of, n, lane);
+  {
+    uint4 buf[WAVE / 4];
+#pragma unroll
+    for (int i = 0; i < WAVE / 4; ++i) {
+      const int q = i * WAVE + lane, r = q >> 4, c = q & 15;
+      buf[i] = make_uint4(0, 0, 0, 0);
+      if (r < n) buf[i] = *reinterpret_cast<const uint4*>(a.rec + (size_t)env_of[r] * REC_BYTES + c * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < WAVE / 4; ++i) {
+      const int q = i * WAVE + lane, r = q >> 4, c = q & 15;
+      if (r < n) *reinterpret_cast<uint4*>(lds + r * LP + c * 16) = buf[i];
+    }
+  }
   __syncthreads();
 
   constexpr bool ADV_OUT = (OP == OP_RESET || OP == OP_STEP_ADV || OP == OP_READ_ENC);
   float z[52];
   bool done = false;
-  if (lane < n) {
-    Env e = make_env(lds + lane * LP, a.seed[env]);
+  if (lane < n && OP != OP_READ_ENC) {
+    Env e = make_env(as_lds(lds + lane * LP), a.seed[env]);
     Metrics m = a.met[env];
     float* zp = (ADV_OUT && a.adv.random_z) ? z : nullptr;
     if (OP == OP_RESET) {
       env_reset(e, p, m, zp);
-      e.put16(DYN + 6, 0);                          // TimeLimit.reset (time_limit.py:35-37)
-      e.set_ep_ret(0.f); e.put16(DYN + 8, 0);       // VecMonitor.reset (vec_monitor.py:36-40)
+      e.elapsed = 0;                                // TimeLimit.reset (time_limit.py:35-37)
+      e.ep_ret = 0.f; e.ep_len = 0;                 // VecMonitor.reset (vec_monitor.py:36-40)
     } else if (OP == OP_STEP_ADV) {
       done = env_step_adversary(e, p, m, a.loc[env], zp);
     } else if (OP == OP_RESET_AGENT) {
       reset_agent(e);
-      e.put16(DYN + 6, 0);                          // time_limit.py:47-49
-      e.set_ep_ret(0.f); e.put16(DYN + 8, 0);       // vec_monitor.py:42-46
+      e.elapsed = 0;                                // time_limit.py:47-49
+      e.ep_ret = 0.f; e.ep_len = 0;                 // vec_monitor.py:42-46
     } else if (OP == OP_RESET_RANDOM) {
       env_reset_random(e, p, m);
-      e.put16(DYN + 6, 0);                          // time_limit.py:39-41
-      e.set_ep_ret(0.f); e.put16(DYN + 8, 0);       // vec_monitor.py:48-52
+      e.elapsed = 0;                                // time_limit.py:39-41
+      e.ep_ret = 0.f; e.ep_len = 0;                 // vec_monitor.py:48-52
     } else if (OP == OP_SET_ENCODING) {
       env_reset(e, p, m, nullptr);                  // adversarial.py:272
-      e.put16(DYN + 6, 0);                          // time_limit.py:43-45
+      e.elapsed = 0;                                // time_limit.py:43-45
       env_set_encoding(e, p, m, a.enc + (size_t)row * S * S * 3);
     } else if (OP == OP_REPLAY) {
       env_reset(e, p, m, nullptr);
-      e.put16(DYN + 6, 0);
+      e.elapsed = 0;
       const int L = a.lens[row];
       if (p.resample_n_clutter) e.sb(7) = (uint8_t)L;                       // adversarial.py:277-278
       for (int k = 0; k < L; ++k)
@@ -232,14 +328,10 @@ __global__ void __launch_bounds__(WAVE) mg_level_kernel(Params p, LevelArgs a) {
     } else if (OP == OP_MUTATE) {
       env_mutate_level(e, p, m, a.num_edits);
     }
-    if (OP != OP_READ_ENC) {
-      a.met[env] = m;
-      raise(a.errs, e.err, env);
-    }
-    if (!ADV_OUT) {
-      if (e.has_pos()) { render_view(e, p, sobs + lane * OPI); sobs[lane * OPI + E] = e.adir(); }
-      else for (int i = 0; i <= E; ++i) sobs[lane * OPI + i] = 0;
-    } else if (OP != OP_READ_ENC) {
+    e.store_dyn();
+    a.met[env] = m;
+    raise(a.errs, e.err, env);
+    if (ADV_OUT) {
       if (a.adv.time_step) a.adv.time_step[env] = (float)e.sb(6);
       if (a.adv.random_z) for (int k = 0; k < p.random_z_dim; ++k) a.adv.random_z[(size_t)env * p.random_z_dim + k] = z[k];
       if (a.adv_done) a.adv_done[env] = done ? 1 : 0;
@@ -248,19 +340,19 @@ __global__ void __launch_bounds__(WAVE) mg_level_kernel(Params p, LevelArgs a) {
   __syncthreads();
   if (OP != OP_READ_ENC) stage_out(lds, a.rec, env_of, n, lane);
   if (ADV_OUT) {
-    // full-grid observation, [x][y][c] u8 and CHW fp32/10 — contiguous per wave (identity rows only)
+    // full-grid observation, [x][y][c] u8 and CHW fp32/10 — contiguous per workgroup (identity rows only)
     const int G = S * S * 3;
     uint8_t* u8 = (OP == OP_READ_ENC) ? a.enc_out : a.adv.image_u8;
     if (u8) for (int f = lane; f < n * G; f += WAVE) {
       const int r = f / G, el = f - r * G, cell = el / 3, c = el - cell * 3, x = cell / S, y = cell - x * S;
-      u8[(size_t)row0 * G + f] = (uint8_t)(enc3(lds[r * LP + y * ROW + x]) >> (8 * c));
+      u8[(size_t)row0 * G + f] = (uint8_t)(lut.enc[lds[r * LP + y * ROW + x]] >> (8 * c));
     }
     if (OP != OP_READ_ENC && a.adv.image_f32) for (int f = lane; f < n * G; f += WAVE) {
       const int r = f / G, el = f - r * G, c = el / (S * S), cell = el - c * S * S, x = cell / S, y = cell - x * S;
-      a.adv.image_f32[(size_t)row0 * G + f] = lut[(uint8_t)(enc3(lds[r * LP + y * ROW + x]) >> (8 * c))];
+      a.adv.image_f32[(size_t)row0 * G + f] = lut.div10[(lut.enc[lds[r * LP + y * ROW + x]] >> (8 * c)) & 15];
     }
   } else {
-    emit_student(sobs, lut, a.stu, (size_t)row0, n, p.V, lane, nullptr);
+    render_emit_v(lds, lut, a.stu, (size_t)row0, n, S, p.V, lane);
   }
 }
 
@@ -272,31 +364,35 @@ __global__ void set_seed_kernel(uint8_t* rec, uint32_t* seed, const int64_t* see
   r[8 * ROW + 15] = 0; r[9 * ROW + 15] = 0; r[10 * ROW + 15] = 0; r[11 * ROW + 15] = 0;
 }
 
-__global__ void init_records_kernel(Params p, uint8_t* rec, uint32_t* seed, Metrics* met, long long base) {
+__global__ void __launch_bounds__(WAVE) init_records_kernel(Params p, uint8_t* rec, uint32_t* seed, Metrics* met, long long base) {
   // MultiGridEnv.__init__ -> reset() (multigrid.py:463): every env starts as an empty walled grid
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVE * LP];
+  const int i = blockIdx.x * WAVE + threadIdx.x;
   if (i >= p.B) return;
-  uint8_t* r = rec + (size_t)i * REC_BYTES;
-  for (int k = 0; k < REC_BYTES; ++k) r[k] = 0;
+  uint8_t* l = lds + threadIdx.x * LP;
+  for (int k = 0; k < REC_BYTES; ++k) l[k] = 0;
   seed[i] = (uint32_t)(base + i);
-  Env e = make_env(r, seed[i]);
+  Env e = make_env(as_lds(l), seed[i]);
   e.sb(7) = (uint8_t)(p.n_clutter + 2);             // adversary_max_steps (adversarial.py:107)
   Metrics m;
   env_reset(e, p, m, nullptr);
+  e.store_dyn();
   met[i] = m;
+  for (int k = 0; k < REC_BYTES; k += 16) *reinterpret_cast<uint4*>(rec + (size_t)i * REC_BYTES + k) = *reinterpret_cast<const uint4*>(l + k);
 }
 
-__global__ void get_state_kernel(Params p, const uint8_t* rec, int32_t* out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(WAVE) get_state_kernel(Params p, const uint8_t* rec, int32_t* out) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVE * LP];
+  const int i = blockIdx.x * WAVE + threadIdx.x;
   if (i >= p.B) return;
-  uint8_t tmp[REC_BYTES];
-  for (int k = 0; k < REC_BYTES; ++k) tmp[k] = rec[(size_t)i * REC_BYTES + k];
-  Env e = make_env(tmp, 0);
+  uint8_t* l = lds + threadIdx.x * LP;
+  for (int k = 0; k < REC_BYTES; k += 16) *reinterpret_cast<uint4*>(l + k) = *reinterpret_cast<const uint4*>(rec + (size_t)i * REC_BYTES + k);
+  Env e = make_env(as_lds(l), 0);
   int32_t* o = out + (size_t)i * 16;
-  o[0] = e.has_pos() ? e.ax() : -1; o[1] = e.has_pos() ? e.ay() : -1; o[2] = e.adir();
-  o[3] = e.carrying() ? (int32_t)enc3(e.carrying()) : 0;
-  o[4] = e.get16(DYN + 4); o[5] = e.get16(DYN + 6); o[6] = e.get16(DYN + 8);
-  float f = e.ep_ret(); memcpy(&o[7], &f, 4);
+  o[0] = e.has_pos() ? e.ax : -1; o[1] = e.has_pos() ? e.ay : -1; o[2] = e.adir;
+  o[3] = e.carrying ? (int32_t)enc3((uint8_t)e.carrying) : 0;
+  o[4] = e.step_count; o[5] = e.elapsed; o[6] = e.ep_len;
+  float f = e.ep_ret; memcpy(&o[7], &f, 4);
   o[8] = e.sb(0) != NOPOS ? e.sb(0) : -1; o[9] = e.sb(0) != NOPOS ? e.sb(1) : -1; o[10] = e.sb(2);
   o[11] = e.sb(3) != NOPOS ? e.sb(3) : -1; o[12] = e.sb(3) != NOPOS ? e.sb(4) : -1;
   o[13] = e.sb(6); o[14] = e.sb(7); o[15] = (int32_t)e.ctr();
@@ -312,12 +408,13 @@ __global__ void get_metrics_kernel(int B, const Metrics* met, int32_t* ncl, int3
   if (dist) dist[i] = m.distance_to_goal;
 }
 
-__global__ void random_actions_kernel(int64_t* actions, int B, long long base, uint32_t seed, uint32_t t, int num_actions) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B) return;
+__global__ void random_actions_kernel(int64_t* actions, int B, int T, long long base, uint32_t seed, uint32_t t0, int num_actions) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (long long)B * T) return;
+  const int t = (int)(q / B), i = (int)(q - (long long)t * B);
   uint32_t o[4];
-  philox4x32_10(t, 0, 0, 0, seed, (uint32_t)(base + i), o);
-  actions[i] = (int64_t)mulhi32(o[0], (uint32_t)num_actions);
+  philox4x32_10(t0 + t, 0, 0, 0, seed, (uint32_t)(base + i), o);
+  actions[q] = (int64_t)mulhi32(o[0], (uint32_t)num_actions);
 }
 
 }  // namespace
@@ -331,6 +428,11 @@ struct DcdMg {
   uint32_t* seed;
   Metrics* met;
   uint32_t* errs;      // [0] bits, [1] first env
+  unsigned long long* stamps = nullptr;   // diagnostic build only
+  // per-launch event pairs while profiling (dcd_mg_profile_begin/end)
+  std::vector<hipEvent_t> ev;
+  int ev_used = 0;
+  bool profiling = false;
 };
 
 namespace dcd {
@@ -347,6 +449,8 @@ int fail(const char* fmt, ...) {
 #define CHECK_H(h) do { if (!(h)) return dcd::fail("null handle"); } while (0)
 
 static inline int nblk(int n) { return (n + 63) / 64; }
+// envs per workgroup of the step kernel: keep >= ~2 workgroups per CU (256 CUs) before widening
+static inline int step_epb(int B) { return B >= 64 * 512 ? 64 : (B >= 32 * 512 ? 32 : 16); }
 
 static LevelArgs base_args(DcdMg* h) {
   LevelArgs a; memset(&a, 0, sizeof a);
@@ -394,7 +498,7 @@ int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out) {
   }
   const uint32_t init[2] = {0u, 0x7fffffffu};
   HIP_OK(hipMemcpy(h->errs, init, 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(init_records_kernel, dim3((p.B + 255) / 256), dim3(256), 0, 0, p, h->rec, h->seed, h->met,
+  hipLaunchKernelGGL(init_records_kernel, dim3((p.B + 63) / 64), dim3(64), 0, 0, p, h->rec, h->seed, h->met,
                      (long long)cfg->env_index_base);
   HIP_OK(hipGetLastError());
   HIP_OK(hipDeviceSynchronize());
@@ -406,6 +510,7 @@ int dcd_mg_destroy(DcdMg* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipFree(h->rec); (void)hipFree(h->seed); (void)hipFree(h->met); (void)hipFree(h->errs);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   delete h;
   return 0;
 }
@@ -480,9 +585,47 @@ int dcd_mg_step(DcdMg* h, const int64_t* actions, int32_t flags, const DcdStepOu
   if (!actions) return dcd::fail("dcd_mg_step: null actions");
   StepArgs a; memset(&a, 0, sizeof a);
   a.rec = h->rec; a.seed = h->seed; a.met = h->met; a.errs = h->errs; a.actions = actions; a.flags = flags;
+  a.stamps = h->stamps;
   if (out) a.out = *out;
-  hipLaunchKernelGGL(mg_step_kernel<false>, dim3(nblk(h->p.B)), dim3(WAVE), 0, (hipStream_t)stream, h->p, a);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) { e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1]; h->ev_used += 2; }
+  const int epb = step_epb(h->p.B);
+  const dim3 grid((h->p.B + epb - 1) / epb), block(WAVE);
+  if (epb == 16) hipExtLaunchKernelGGL((mg_step_kernel<false, 16>), grid, block, 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
+  else if (epb == 32) hipExtLaunchKernelGGL((mg_step_kernel<false, 32>), grid, block, 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
+  else hipExtLaunchKernelGGL((mg_step_kernel<false, 64>), grid, block, 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// diagnostic builds (-DDCD_STAMPS) only; not part of include/dcd_hip.h
+int dcd_internal_set_stamps(DcdMg* h, unsigned long long* dev_ptr) { if (!h) return 1; h->stamps = dev_ptr; return 0; }
+
+int dcd_mg_profile_begin(DcdMg* h, int32_t capacity) {
+  CHECK_H(h);
+  if (capacity <= 0 || capacity > (1 << 20)) return dcd::fail("dcd_mg_profile_begin: bad capacity %d", capacity);
+  while ((int)h->ev.size() < 2 * capacity) {
+    hipEvent_t e;
+    HIP_OK(hipEventCreate(&e));
+    h->ev.push_back(e);
+  }
+  h->ev_used = 0; h->profiling = true;
+  return 0;
+}
+
+int dcd_mg_profile_end(DcdMg* h, int32_t* n_launches, double* total_ms, void* stream) {
+  CHECK_H(h);
+  h->profiling = false;
+  HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+  double tot = 0.0;
+  for (int i = 0; i + 1 < h->ev_used; i += 2) {
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    tot += ms;
+  }
+  if (n_launches) *n_launches = h->ev_used / 2;
+  if (total_ms) *total_ms = tot;
+  h->ev_used = 0;
   return 0;
 }
 
@@ -495,7 +638,11 @@ int dcd_mg_step_random(DcdMg* h, uint32_t action_seed, uint32_t t0, int32_t K, i
   a.K = K; a.action_seed = action_seed; a.t0 = t0; a.env_index_base = h->cfg.env_index_base;
   a.n_episodes = reinterpret_cast<unsigned long long*>(n_episodes);
   if (out) a.out = *out;
-  hipLaunchKernelGGL(mg_step_kernel<true>, dim3(nblk(h->p.B)), dim3(WAVE), 0, (hipStream_t)stream, h->p, a);
+  const int epb = step_epb(h->p.B);
+  const dim3 grid((h->p.B + epb - 1) / epb), block(WAVE);
+  if (epb == 16) hipLaunchKernelGGL((mg_step_kernel<true, 16>), grid, block, 0, (hipStream_t)stream, h->p, a);
+  else if (epb == 32) hipLaunchKernelGGL((mg_step_kernel<true, 32>), grid, block, 0, (hipStream_t)stream, h->p, a);
+  else hipLaunchKernelGGL((mg_step_kernel<true, 64>), grid, block, 0, (hipStream_t)stream, h->p, a);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -519,9 +666,10 @@ int dcd_mg_get_state(DcdMg* h, int32_t* out, void* stream) {
   HIP_OK(hipGetLastError());
   return 0;
 }
-int dcd_random_actions(int64_t* actions, int32_t B, int64_t base, uint32_t seed, uint32_t t, int32_t num_actions, void* stream) {
-  if (!actions || B <= 0) return dcd::fail("dcd_random_actions: bad arguments");
-  hipLaunchKernelGGL(random_actions_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, actions, B, (long long)base, seed, t, num_actions);
+int dcd_random_actions(int64_t* actions, int32_t B, int32_t T, int64_t base, uint32_t seed, uint32_t t0, int32_t num_actions, void* stream) {
+  if (!actions || B <= 0 || T <= 0) return dcd::fail("dcd_random_actions: bad arguments");
+  const long long total = (long long)B * T;
+  hipLaunchKernelGGL(random_actions_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, actions, B, T, (long long)base, seed, t0, num_actions);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -199,6 +199,15 @@ class MultiGridEngine:
                                        ptr(n_episodes, torch.int64, 1, "n_episodes"), stream_ptr()))
         return out
 
+    def profile_begin(self, capacity):
+        check(lib().dcd_mg_profile_begin(self._h, C.c_int32(capacity)))
+
+    def profile_end(self):
+        """Synchronises; returns (launches, total kernel milliseconds) of the bracketed dcd_mg_step calls."""
+        n, ms = C.c_int32(0), C.c_double(0.0)
+        check(lib().dcd_mg_profile_end(self._h, C.byref(n), C.byref(ms), stream_ptr()))
+        return int(n.value), float(ms.value)
+
     def get_encodings(self):
         out = torch.empty((self.B, self.S, self.S, 3), dtype=torch.uint8, device=self.device)
         check(lib().dcd_mg_get_encodings(self._h, ptr(out), stream_ptr()))
@@ -215,8 +224,11 @@ class MultiGridEngine:
         return out
 
 
-def random_actions(B, env_index_base, seed, t, num_actions, device, out=None):
-    out = torch.empty((B,), dtype=torch.int64, device=device) if out is None else out
-    check(lib().dcd_random_actions(ptr(out, torch.int64, B, "actions"), C.c_int32(B), C.c_int64(env_index_base),
-                                   C.c_uint32(seed), C.c_uint32(t), C.c_int32(num_actions), stream_ptr()))
+def random_actions(B, env_index_base, seed, t, num_actions, device, out=None, T=1):
+    """Synthetic Philox actions: int64[B] (T == 1) or int64[T,B] for steps t .. t+T-1."""
+    if out is None:
+        out = torch.empty((B,) if T == 1 else (T, B), dtype=torch.int64, device=device)
+    check(lib().dcd_random_actions(ptr(out, torch.int64, B * T, "actions"), C.c_int32(B), C.c_int32(T),
+                                   C.c_int64(env_index_base), C.c_uint32(seed), C.c_uint32(t), C.c_int32(num_actions),
+                                   stream_ptr()))
     return out

@@ -184,6 +184,14 @@ int dcd_mg_mutate_level(DcdMg* h, int32_t num_edits, const DcdStudentObs* out, v
 int dcd_mg_step(DcdMg* h, const int64_t* actions, int32_t flags, const DcdStepOut* out,
                 void* stream);
 
+/* Per-launch timing of the step kernel for the roofline line of bench.py: between begin and end
+ * every dcd_mg_step launch on this handle is bracketed by HIP events attached to the dispatch
+ * itself (hipExtLaunchKernelGGL start/stop events: the same begin/end timestamps rocprofv3
+ * --kernel-trace reports).  end() synchronises the stream and returns the number of launches
+ * and their summed duration in milliseconds.  capacity: max launches recorded. */
+int dcd_mg_profile_begin(DcdMg* h, int32_t capacity);
+int dcd_mg_profile_end(DcdMg* h, int32_t* n_launches, double* total_ms, void* stream);
+
 /* ---- state readback -------------------------------------------------------- */
 /* venv.get_encodings (parallel_wrappers.py:420-421 → adversarial.py:162-164):
  * uint8[B,S,S,3]. */
@@ -281,9 +289,10 @@ int dcd_env_return(const float* agent_mean, const float* agent_max, const float*
                    const float* adv_max, float* out, int32_t B, int32_t mode, void* stream);
 
 /* ---- synthetic workload helpers (bench / tests only) ------------- */
-/* actions[i] = mulhi(philox(key=(seed, env_index_base+i), ctr=(t,0,0,0))[0], num_actions) */
-int dcd_random_actions(int64_t* actions, int32_t B, int64_t env_index_base, uint32_t seed,
-                       uint32_t t, int32_t num_actions, void* stream);
+/* actions[t,i] = mulhi(philox(key=(seed, env_index_base+i), ctr=(t0+t,0,0,0))[0], num_actions);
+ * actions: int64[T,B] */
+int dcd_random_actions(int64_t* actions, int32_t B, int32_t T, int64_t env_index_base, uint32_t seed,
+                       uint32_t t0, int32_t num_actions, void* stream);
 /* K fused random-action student steps in one launch (grid stays in LDS): the
  * random-agent rollout of models/multigrid_models.py:149-157 without a host round
  * trip.  Outputs of the LAST step only (any may be NULL); counters accumulate

@@ -833,3 +833,22 @@ void orc_view_to_world(int ax, int ay, int dir, int V, int vx, int vy, int* wx, 
   *wx = tlx - fx * vy + rx * vx;
   *wy = tly - fy * vy + ry * vx;
 }
+
+/* cpu_baseline leg of bench.py: T student steps of envs [lo,hi) with the synthetic Philox action
+ * stream (same as dcd_random_actions), every step emitting the full StepOut into `out` (rows
+ * lo..hi-1 of single-step buffers, overwritten each step).  One call per host thread. */
+int64_t orc_mg_rollout_range(OrcMg* h, const DcdStepOut* out, int32_t lo, int32_t hi, int32_t T,
+                             uint32_t action_seed, uint32_t t0, int32_t last_flag) {
+  int64_t episodes = 0;
+  for (int t = 0; t < T; ++t) {
+    int32_t flags = (last_flag && t == T - 1) ? DCD_STEP_LAST : 0;
+    for (int b = lo; b < hi; ++b) {
+      uint32_t o[4];
+      philox4x32_10(t0 + (uint32_t)t, 0, 0, 0, action_seed, (uint32_t)(h->cfg.env_index_base + b), o);
+      int64_t a = (int64_t)(((uint64_t)o[0] * 7u) >> 32);
+      orc_step_one(h, b, a, flags, out);
+      if (out && out->info) episodes += (out->info[b] & DCD_INFO_EPISODE) ? 1 : 0;
+    }
+  }
+  return episodes;
+}

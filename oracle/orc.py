@@ -73,6 +73,7 @@ def lib():
         _lib.orc_mg_create.restype = C.c_void_p
         _lib.orc_mg_poll_errors.restype = C.c_uint32
         _lib.orc_episode_scores.restype = C.c_int32
+        _lib.orc_mg_rollout_range.restype = C.c_int64
     return _lib
 
 
@@ -203,6 +204,11 @@ class OracleMg:
 
     def step_range(self, actions, flags, st, lo, hi):
         self._fn("step_range")(self.h, _p(actions), C.c_int32(flags), C.byref(st), C.c_int32(lo), C.c_int32(hi))
+
+    def rollout_range(self, st, lo, hi, T, action_seed, t0, last_flag=1):
+        """T fused steps of envs [lo,hi) with Philox actions (cpu_baseline leg; GIL released)."""
+        return self._fn("rollout_range")(self.h, C.byref(st), C.c_int32(lo), C.c_int32(hi), C.c_int32(T),
+                                         C.c_uint32(action_seed), C.c_uint32(t0), C.c_int32(last_flag))
 
     def get_encodings(self):
         out = np.zeros((self.B, self.S, self.S, 3), np.uint8)

@@ -35,7 +35,7 @@ static void emit_student_row(SimMg* h, Env& e, int row, const DcdStudentObs* o, 
   const int V = h->p.V, E = V * V * 3;
   uint8_t img[DCD_MAX_VIEW * DCD_MAX_VIEW * 3 + 1];
   if (img_in) memcpy(img, img_in, E + 1);
-  else if (e.has_pos()) { render_view(e, h->p, img); img[E] = e.adir(); }
+  else if (e.has_pos()) { render_view(e, h->p, img); img[E] = (uint8_t)e.adir; }
   else memset(img, 0, sizeof img);
   if (o->image_u8) memcpy(o->image_u8 + (size_t)row * E, img, E);
   if (o->dir_u8) o->dir_u8[row] = img[E];
@@ -79,6 +79,7 @@ SimMg* sim_mg_create(const DcdMgConfig* cfg) {
     Env e = make_env(&h->rec[(size_t)i * REC_BYTES], h->seed[i]);
     e.sb(7) = (uint8_t)(p.n_clutter + 2);
     env_reset(e, p, h->met[i], nullptr);
+    e.store_dyn();
   }
   return h;
 }
@@ -101,8 +102,8 @@ void sim_mg_reset(SimMg* h, const DcdAdvObs* out) {
   for (int i = 0; i < h->p.B; ++i) {
     ENV(i);
     env_reset(e, h->p, m, z);
-    e.put16(DYN + 6, 0); e.set_ep_ret(0.f); e.put16(DYN + 8, 0);
-    emit_adv_row(h, e, i, out, z); note(h, i, e.err);
+    e.elapsed = 0; e.ep_ret = 0.f; e.ep_len = 0;
+    e.store_dyn(); emit_adv_row(h, e, i, out, z); note(h, i, e.err);
   }
 }
 void sim_mg_step_adversary(SimMg* h, const int64_t* loc, const DcdAdvObs* out, uint8_t* done) {
@@ -111,23 +112,23 @@ void sim_mg_step_adversary(SimMg* h, const int64_t* loc, const DcdAdvObs* out, u
     ENV(i);
     bool d = env_step_adversary(e, h->p, m, loc[i], z);
     if (done) done[i] = d;
-    emit_adv_row(h, e, i, out, z); note(h, i, e.err);
+    e.store_dyn(); emit_adv_row(h, e, i, out, z); note(h, i, e.err);
   }
 }
 void sim_mg_reset_agent(SimMg* h, const DcdStudentObs* out) {
   for (int i = 0; i < h->p.B; ++i) {
     ENV(i); (void)m;
     reset_agent(e);
-    e.put16(DYN + 6, 0); e.set_ep_ret(0.f); e.put16(DYN + 8, 0);
-    emit_student_row(h, e, i, out, nullptr); note(h, i, e.err);
+    e.elapsed = 0; e.ep_ret = 0.f; e.ep_len = 0;
+    e.store_dyn(); emit_student_row(h, e, i, out, nullptr); note(h, i, e.err);
   }
 }
 void sim_mg_reset_random(SimMg* h, const DcdStudentObs* out) {
   for (int i = 0; i < h->p.B; ++i) {
     ENV(i);
     env_reset_random(e, h->p, m);
-    e.put16(DYN + 6, 0); e.set_ep_ret(0.f); e.put16(DYN + 8, 0);
-    emit_student_row(h, e, i, out, nullptr); note(h, i, e.err);
+    e.elapsed = 0; e.ep_ret = 0.f; e.ep_len = 0;
+    e.store_dyn(); emit_student_row(h, e, i, out, nullptr); note(h, i, e.err);
   }
 }
 void sim_mg_reset_to_encoding(SimMg* h, const uint8_t* enc, const int32_t* idx, int32_t n, const DcdStudentObs* out) {
@@ -136,9 +137,9 @@ void sim_mg_reset_to_encoding(SimMg* h, const uint8_t* enc, const int32_t* idx, 
     const int i = idx ? idx[r] : r;
     ENV(i);
     env_reset(e, h->p, m, nullptr);
-    e.put16(DYN + 6, 0);
+    e.elapsed = 0;
     env_set_encoding(e, h->p, m, enc + (size_t)r * S * S * 3);
-    emit_student_row(h, e, r, out, nullptr); note(h, i, e.err);
+    e.store_dyn(); emit_student_row(h, e, r, out, nullptr); note(h, i, e.err);
   }
 }
 void sim_mg_reset_to_actions(SimMg* h, const int64_t* actions, const int32_t* lens, int32_t max_len, const int32_t* idx, int32_t n,
@@ -147,18 +148,18 @@ void sim_mg_reset_to_actions(SimMg* h, const int64_t* actions, const int32_t* le
     const int i = idx ? idx[r] : r;
     ENV(i);
     env_reset(e, h->p, m, nullptr);
-    e.put16(DYN + 6, 0);
+    e.elapsed = 0;
     if (h->p.resample_n_clutter) e.sb(7) = (uint8_t)lens[r];
     for (int k = 0; k < lens[r]; ++k)
       if (env_step_adversary(e, h->p, m, actions[(size_t)r * max_len + k], nullptr)) reset_agent(e);
-    emit_student_row(h, e, r, out, nullptr); note(h, i, e.err);
+    e.store_dyn(); emit_student_row(h, e, r, out, nullptr); note(h, i, e.err);
   }
 }
 void sim_mg_mutate_level(SimMg* h, int32_t num_edits, const DcdStudentObs* out) {
   for (int i = 0; i < h->p.B; ++i) {
     ENV(i);
     env_mutate_level(e, h->p, m, num_edits);
-    emit_student_row(h, e, i, out, nullptr); note(h, i, e.err);
+    e.store_dyn(); emit_student_row(h, e, i, out, nullptr); note(h, i, e.err);
   }
 }
 void sim_mg_step(SimMg* h, const int64_t* actions, int32_t flags, const DcdStepOut* out) {
@@ -168,6 +169,7 @@ void sim_mg_step(SimMg* h, const int64_t* actions, int32_t flags, const DcdStepO
     bool md = false;
     uint8_t term[DCD_MAX_VIEW * DCD_MAX_VIEW * 3 + 1];
     StepResult r = env_step(e, h->p, m, md, actions[i], flags, term);
+    e.store_dyn();
     note(h, i, e.err);
     if (!out) continue;
     emit_student_row(h, e, i, &out->obs, nullptr);
@@ -206,10 +208,10 @@ void sim_mg_get_state(SimMg* h, int32_t* out) {
   for (int i = 0; i < h->p.B; ++i) {
     ENV(i); (void)m;
     int32_t* o = out + (size_t)i * 16;
-    o[0] = e.has_pos() ? e.ax() : -1; o[1] = e.has_pos() ? e.ay() : -1; o[2] = e.adir();
-    o[3] = e.carrying() ? (int32_t)enc3(e.carrying()) : 0;
-    o[4] = e.get16(DYN + 4); o[5] = e.get16(DYN + 6); o[6] = e.get16(DYN + 8);
-    float f = e.ep_ret(); memcpy(&o[7], &f, 4);
+    o[0] = e.has_pos() ? e.ax : -1; o[1] = e.has_pos() ? e.ay : -1; o[2] = e.adir;
+    o[3] = e.carrying ? (int32_t)enc3((uint8_t)e.carrying) : 0;
+    o[4] = e.step_count; o[5] = e.elapsed; o[6] = e.ep_len;
+    float f = e.ep_ret; memcpy(&o[7], &f, 4);
     o[8] = e.sb(0) != NOPOS ? e.sb(0) : -1; o[9] = e.sb(0) != NOPOS ? e.sb(1) : -1; o[10] = e.sb(2);
     o[11] = e.sb(3) != NOPOS ? e.sb(3) : -1; o[12] = e.sb(3) != NOPOS ? e.sb(4) : -1;
     o[13] = e.sb(6); o[14] = e.sb(7); o[15] = (int32_t)e.ctr();

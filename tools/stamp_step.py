@@ -1,0 +1,35 @@
+"""Diagnostic: phase breakdown of mg_step_kernel from in-kernel s_memtime stamps.
+Builds a SEPARATE library with -DDCD_STAMPS (never the shipped one) and prints median cycles per phase."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dcd-isaac_amd")); sys.path.insert(0, ROOT)
+import torch
+csrc = os.path.join(ROOT, "dcd-isaac_amd", "csrc")
+out = os.path.join(ROOT, "gpurun_out", "libdcd_hip_stamps.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                       "-DDCD_STAMPS", "-shared", "-o", out, os.path.join(csrc, "mg_kernels.hip"), os.path.join(csrc, "scan_kernels.hip")])
+import dcd_hip
+dcd_hip.LIB_PATH = out
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+eng = dcd_hip.MultiGridEngine(B, n_clutter=25, choose_goal_last=1)
+eng.reset_random()
+nblk = (B + 15) // 16 if B < 32 * 512 else ((B + 31) // 32 if B < 64 * 512 else (B + 63) // 64)
+st = torch.zeros((nblk, 8), dtype=torch.int64, device="cuda")
+dcd_hip.lib().dcd_internal_set_stamps(eng._h, C.c_void_p(st.data_ptr()))
+outb = eng.step_buffers(u8=False)
+names = ["init_luts", "stage_in", "logic", "dyn store+writeback", "render_emit", "term emit"]
+import numpy as np
+acc = []
+for t in range(50):
+    a = dcd_hip.engine.random_actions(B, 0, 3, t, 7, "cuda")
+    eng.step(a, 0, outb)
+    torch.cuda.synchronize()
+    s = st.cpu().numpy()
+    acc.append(np.diff(s[:, :7], axis=1))
+    span = (s[:, 6].max() - s[:, 0].min())
+acc = np.stack(acc[5:])
+med = np.median(acc, axis=(0, 1))
+for n, m in zip(names, med):
+    print(f"{n:24s} {m:9.0f} cycles")
+print("per-block total median", np.median(acc.sum(-1)), "cycles; grid span last launch", span)
