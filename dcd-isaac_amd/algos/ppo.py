@@ -1,0 +1,117 @@
+"""PPO-clip with clipped value loss (reference: algos/ppo.py:19-146), plus the data-parallel hooks
+the reference does not have: when a `torch.distributed` process group is passed, advantage
+normalisation uses global moments, losses/entropies are averaged over the global minibatch and
+gradients are all-reduced (RCCL over xGMI on MI355X) before clipping — so N ranks × B envs equal
+one process with N·B envs.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.optim as optim
+
+
+class PPO:
+    def __init__(self, actor_critic, clip_param, ppo_epoch, num_mini_batch, value_loss_coef, entropy_coef,
+                 lr=None, eps=None, max_grad_norm=None, clip_value_loss=True, log_grad_norm=False,
+                 process_group=None):
+        self.actor_critic = actor_critic
+        self.clip_param = clip_param
+        self.ppo_epoch = ppo_epoch
+        self.num_mini_batch = num_mini_batch
+        self.clip_value_loss = clip_value_loss
+        self.value_loss_coef = value_loss_coef
+        self.entropy_coef = entropy_coef
+        self.max_grad_norm = max_grad_norm
+        self.optimizer = optim.Adam(actor_critic.parameters(), lr=lr, eps=eps)
+        self.log_grad_norm = log_grad_norm
+        self.process_group = process_group
+        self._flat_grad = None
+
+    # ---- distributed helpers ----------------------------------------------------------------
+    @property
+    def world_size(self):
+        if self.process_group is None:
+            return 1
+        import torch.distributed as dist
+        return dist.get_world_size(self.process_group)
+
+    def _all_reduce(self, t):
+        if self.process_group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.process_group)
+        return t
+
+    def _normalize_advantages(self, adv):
+        """(adv - mean) / (std + 1e-5) with unbiased std (ppo.py:67-69), moments over ALL ranks."""
+        if self.world_size == 1:
+            return (adv - adv.mean()) / (adv.std() + 1e-5)
+        s = torch.stack([adv.sum().double(), (adv.double() ** 2).sum(),
+                         torch.tensor(float(adv.numel()), dtype=torch.float64, device=adv.device)])
+        self._all_reduce(s)
+        n = s[2]
+        mean = s[0] / n
+        var = (s[1] - n * mean * mean) / (n - 1)
+        return (adv - mean.float()) / (var.clamp_min(0).sqrt().float() + 1e-5)
+
+    def _sync_gradients(self):
+        """One bucketed all-reduce of the flattened gradient (1.7 MB student / 90 MB teacher)."""
+        if self.world_size == 1:
+            return
+        params = [p for p in self.actor_critic.parameters() if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        self._all_reduce(flat)
+        flat /= self.world_size
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+
+    def _grad_norm(self):
+        total = 0.0
+        for p in self.actor_critic.parameters():
+            if p.grad is not None:
+                total += p.grad.data.norm(2).item() ** 2
+        return total ** 0.5
+
+    # ---- update -------------------------------------------------------------------------------
+    def update(self, rollouts, discard_grad=False):
+        advantages = rollouts.returns[:-1] - rollouts.value_preds[:-1]
+        advantages = self._normalize_advantages(advantages)
+        value_loss_epoch = action_loss_epoch = dist_entropy_epoch = 0.0
+        grad_norms = []
+        for _ in range(self.ppo_epoch):
+            gen = (rollouts.recurrent_generator(advantages, self.num_mini_batch) if self.actor_critic.is_recurrent
+                   else rollouts.feed_forward_generator(advantages, self.num_mini_batch))
+            for (obs_b, hxs_b, actions_b, value_preds_b, return_b, masks_b, old_logp_b, adv_b) in gen:
+                values, logp, dist_entropy, _ = self.actor_critic.evaluate_actions(obs_b, hxs_b, masks_b, actions_b)
+                ratio = torch.exp(logp - old_logp_b)
+                surr1 = ratio * adv_b
+                surr2 = torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_b
+                action_loss = -torch.min(surr1, surr2).mean()
+                if self.clip_value_loss:
+                    clipped = value_preds_b + (values - value_preds_b).clamp(-self.clip_param, self.clip_param)
+                    value_loss = 0.5 * torch.max((values - return_b).pow(2), (clipped - return_b).pow(2)).mean()
+                else:
+                    value_loss = F.smooth_l1_loss(values, return_b)
+                self.optimizer.zero_grad()
+                loss = value_loss * self.value_loss_coef + action_loss - dist_entropy * self.entropy_coef
+                loss.backward()
+                self._sync_gradients()
+                if self.log_grad_norm:
+                    grad_norms.append(self._grad_norm())
+                if self.max_grad_norm is not None and self.max_grad_norm > 0:
+                    nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
+                if not discard_grad:
+                    self.optimizer.step()
+                stats = torch.stack([value_loss.detach(), action_loss.detach(), dist_entropy.detach()])
+                if self.world_size > 1:
+                    self._all_reduce(stats)
+                    stats /= self.world_size
+                v, a, e = stats.tolist()
+                value_loss_epoch += v
+                action_loss_epoch += a
+                dist_entropy_epoch += e
+        n = self.ppo_epoch * self.num_mini_batch
+        info = {"grad_norms": grad_norms} if self.log_grad_norm else {}
+        return value_loss_epoch / n, action_loss_epoch / n, dist_entropy_epoch / n, info

@@ -1,0 +1,315 @@
+"""RolloutStorage — device-resident rollout buffers with the reference's fields and methods
+(reference: algos/storage.py:41-517), the scans running as HIP kernels (dcd_hip.scans).
+
+Layout is the reference's: time-major (T+1, B, ...) tensors with the env axis contiguous, which is
+exactly what the one-env-per-lane scan kernels want.  Differences that do not change results:
+  * buffers are allocated directly on `device` and the engine writes observations, rewards and masks
+    straight into the [step] slices (`step_out()`), so there is no per-step host->device copy
+    (reference: ~12 copy_ per step, :155-185);
+  * `_compute_truncated_value_preds` forwards ALL (t, env) pairs with bad_masks == 0 in one batch
+    instead of one net call per env (:208-231) — same inputs per row, fp32 GEMM batching tolerance;
+  * the PPO minibatch generator gathers whole env trajectories with one index_select per tensor
+    instead of a Python loop over envs (:466-480); the permutation draw is the reference's.
+Extra device fields (`ep_ret`, `ep_info`, `dones`) keep per-step episode statistics so that the
+runner's per-env return stats (adversarial_runner.py:257-271) need no host loop.
+"""
+from collections import defaultdict
+
+import torch
+
+from dcd_hip import scans
+
+
+def _flatten(T, N, x):
+    if isinstance(x, dict):
+        return {k: v.reshape(T * N, *v.shape[2:]) for k, v in x.items()}
+    return x.reshape(T * N, *x.shape[2:])
+
+
+class RolloutStorage:
+    def __init__(self, model, num_steps, num_processes, observation_space, action_space,
+                 recurrent_hidden_state_size, recurrent_arch="rnn", use_proper_time_limits=False,
+                 use_popart=False, device="cpu"):
+        if use_popart:
+            raise NotImplementedError("PopArt is off in every MultiGrid config (SURVEY §2 #15); not supported")
+        self.device = torch.device(device)
+        self.model = model
+        self.num_steps, self.num_processes = num_steps, num_processes
+        self.recurrent_arch = recurrent_arch
+        self.recurrent_hidden_state_size = recurrent_hidden_state_size
+        self.is_lstm = recurrent_arch == "lstm"
+        self.use_proper_time_limits = use_proper_time_limits
+        self.use_popart = False
+        T, B, d = num_steps, num_processes, self.device
+        z = lambda *s, **kw: torch.zeros(*s, device=d, **kw)
+        self.is_dict_obs = isinstance(observation_space, dict)
+        self.truncated_obs = None
+        if self.is_dict_obs:
+            self.obs = {k: z(T + 1, B, *sp.shape) for k, sp in observation_space.items()}
+            if use_proper_time_limits:
+                self.truncated_obs = {k: z(T + 1, B, *sp.shape) for k, sp in observation_space.items()}
+        else:
+            self.obs = z(T + 1, B, *observation_space.shape)
+            if use_proper_time_limits:
+                self.truncated_obs = torch.zeros_like(self.obs)
+        hs = 2 * recurrent_hidden_state_size if self.is_lstm else recurrent_hidden_state_size
+        self.recurrent_hidden_states = z(T + 1, B, hs)
+        self.rewards = z(T, B, 1)
+        self.value_preds = z(T + 1, B, 1)
+        self.returns = z(T + 1, B, 1)
+        self.action_log_probs = z(T, B, 1)
+        if action_space.__class__.__name__ == "Discrete":
+            action_shape = 1
+            self.action_log_dist = z(T, B, action_space.n)
+        else:
+            action_shape = action_space.shape[0]
+            self.action_log_dist = z(T, B, 1)
+        self.actions = z(T, B, action_shape)
+        if action_space.__class__.__name__ == "Discrete":
+            self.actions = self.actions.long()
+        self.masks = torch.ones(T + 1, B, 1, device=d)
+        self.bad_masks = torch.ones(T + 1, B, 1, device=d)
+        self.cliffhanger_masks = torch.ones(T + 1, B, 1, device=d)
+        self.truncated_value_preds = torch.zeros_like(self.value_preds) if use_proper_time_limits else None
+        self.denorm_value_preds = None
+        self.level_seeds = z(T, B, 1, dtype=torch.int)
+        # device-side episode statistics of the current rollout (info bits: dcd_hip.INFO_*)
+        self.ep_ret = z(T, B)
+        self.ep_info = z(T, B, dtype=torch.uint8)
+        self.dones = z(T, B, dtype=torch.uint8)
+        self.step = 0
+
+    def to(self, device):
+        device = torch.device(device)
+        self.device = device
+        for name, val in list(vars(self).items()):
+            if isinstance(val, torch.Tensor):
+                setattr(self, name, val.to(device))
+            elif isinstance(val, dict) and val and all(isinstance(v, torch.Tensor) for v in val.values()):
+                setattr(self, name, {k: v.to(device) for k, v in val.items()})
+        return self
+
+    # ---- observation access ---------------------------------------------------------------
+    def get_obs(self, idx):
+        return {k: v[idx] for k, v in self.obs.items()} if self.is_dict_obs else self.obs[idx]
+
+    def copy_obs_to_index(self, obs, index):
+        if self.is_dict_obs:
+            for k in self.obs:
+                self.obs[k][index].copy_(obs[k])
+        else:
+            self.obs[index].copy_(obs)
+
+    def student_obs_out(self, index, truncated=False):
+        """Engine output struct whose fp32 image/direction land in obs[index] (or truncated_obs[index])."""
+        src = self.truncated_obs if truncated else self.obs
+        return {"image_f32": src["image"][index], "dir_f32": src["direction"][index]}
+
+    def adversary_obs_out(self, index):
+        return {"image_f32": self.obs["image"][index], "time_step": self.obs["time_step"][index],
+                "random_z": self.obs["random_z"][index]}
+
+    def step_out(self, step):
+        """DcdStepOut for rollout step `step`: the engine writes obs[step+1], rewards[step], masks[step+1],
+        bad_masks[step+1], cliffhanger_masks[step+1], truncated_obs[step+1] and the episode stats
+        (what adversarial_runner.py:517-585 + storage.insert do on the host in the reference)."""
+        out = dict(obs=self.student_obs_out(step + 1), reward=self.rewards[step].view(-1),
+                   done=self.dones[step], info=self.ep_info[step], ep_ret=self.ep_ret[step],
+                   masks=self.masks[step + 1].view(-1), bad_masks=self.bad_masks[step + 1].view(-1),
+                   cliffhanger_masks=self.cliffhanger_masks[step + 1].view(-1))
+        if self.truncated_obs is not None:
+            out["term_obs"] = self.student_obs_out(step + 1, truncated=True)
+        return out
+
+    # ---- insert (reference :155-203) --------------------------------------------------------
+    def insert(self, obs, recurrent_hidden_states, actions, action_log_probs, action_log_dist, value_preds,
+               rewards, masks, bad_masks, level_seeds=None, cliffhanger_masks=None):
+        if rewards.dim() == 3:
+            rewards = rewards.squeeze(2)
+        self.copy_obs_to_index(obs, self.step + 1)
+        self.insert_policy(recurrent_hidden_states, actions, action_log_probs, action_log_dist, value_preds,
+                           level_seeds)
+        self.rewards[self.step].copy_(rewards)
+        self.masks[self.step + 1].copy_(masks)
+        self.bad_masks[self.step + 1].copy_(bad_masks)
+        if cliffhanger_masks is not None:
+            self.cliffhanger_masks[self.step + 1].copy_(cliffhanger_masks)
+        self.advance()
+
+    def insert_policy(self, recurrent_hidden_states, actions, action_log_probs, action_log_dist, value_preds,
+                      level_seeds=None):
+        """Policy-side half of insert(); the env-side half is written by the engine via step_out()."""
+        s, H = self.step, self.recurrent_hidden_state_size
+        if self.is_lstm:
+            self.recurrent_hidden_states[s + 1, :, :H].copy_(recurrent_hidden_states[0])
+            self.recurrent_hidden_states[s + 1, :, H:].copy_(recurrent_hidden_states[1])
+        else:
+            self.recurrent_hidden_states[s + 1].copy_(recurrent_hidden_states)
+        self.actions[s].copy_(actions)
+        self.action_log_probs[s].copy_(action_log_probs)
+        self.action_log_dist[s].copy_(action_log_dist)
+        self.value_preds[s].copy_(value_preds)
+        if level_seeds is not None:
+            self.level_seeds[s].copy_(level_seeds)
+
+    def advance(self):
+        self.step = (self.step + 1) % self.num_steps
+
+    def insert_truncated_obs(self, obs, index):
+        for k in self.truncated_obs:
+            self.truncated_obs[k][self.step + 1][index].copy_(torch.as_tensor(obs[k]).reshape(
+                self.truncated_obs[k].shape[2:]))
+
+    def after_update(self):
+        if self.is_dict_obs:
+            for k in self.obs:
+                self.obs[k][0].copy_(self.obs[k][-1])
+        else:
+            self.obs[0].copy_(self.obs[-1])
+        self.recurrent_hidden_states[0].copy_(self.recurrent_hidden_states[-1])
+        self.masks[0].copy_(self.masks[-1])
+        self.bad_masks[0].copy_(self.bad_masks[-1])
+        self.cliffhanger_masks[0].copy_(self.cliffhanger_masks[-1])
+
+    def replace_final_return(self, returns):
+        self.rewards[-1] = returns
+
+    # ---- returns --------------------------------------------------------------------------
+    def _compute_truncated_value_preds(self):
+        """value_preds with V(truncated_obs) written wherever bad_masks == 0 (reference :208-231)."""
+        self.truncated_value_preds.copy_(self.value_preds)
+        bad = self.bad_masks[:, :, 0] == 0
+        # Reference quirk (:214-216): `steps = nonzero().squeeze()` is 0-dim when an env has exactly ONE
+        # such step and that env is then skipped — only envs with >= 2 truncated steps are forwarded.
+        bad = bad & (bad.sum(dim=0, keepdim=True) >= 2)
+        t_idx, b_idx = bad.nonzero(as_tuple=True)
+        if t_idx.numel() == 0:
+            return self.truncated_value_preds
+        with torch.no_grad():
+            if self.is_dict_obs:
+                obs = {k: v[t_idx, b_idx] for k, v in self.truncated_obs.items()}
+            else:
+                obs = self.truncated_obs[t_idx, b_idx]
+            hxs = self.recurrent_hidden_states[t_idx, b_idx]
+            if self.is_lstm:
+                hxs = self._split_batched_lstm_recurrent_hidden_states(hxs)
+            ones = torch.ones((t_idx.numel(), 1), device=self.device)
+            self.truncated_value_preds[t_idx, b_idx] = self.model.get_value(obs, hxs, ones)
+        return self.truncated_value_preds
+
+    def _value_source(self, next_value):
+        self.value_preds[-1] = next_value
+        if self.use_proper_time_limits:
+            return self._compute_truncated_value_preds()
+        return self.value_preds
+
+    def compute_gae_returns(self, returns_buffer, next_value, gamma, gae_lambda):
+        scans.gae_returns(self.rewards, self._value_source(next_value), self.masks, returns_buffer, gamma, gae_lambda)
+
+    def compute_discounted_returns(self, returns_buffer, next_value, gamma):
+        scans.discounted_returns(self.rewards, self._value_source(next_value), self.masks, returns_buffer, gamma)
+
+    def compute_returns(self, next_value, use_gae, gamma, gae_lambda):
+        if use_gae:
+            self.compute_gae_returns(self.returns, next_value, gamma, gae_lambda)
+        else:
+            self.compute_discounted_returns(self.returns, next_value, gamma)
+
+    def get_batched_value_loss(self, signed=False, positive_only=False, power=1, clipped=True, batched=True):
+        mode = 1 if signed else (2 if positive_only else 0)
+        out = scans.batched_value_loss(self.returns, self.value_preds, mode, int(power), clipped)
+        return out if batched else out.mean().item()
+
+    # ---- action trajectories ----------------------------------------------------------------
+    def get_action_traj(self, as_string=False):
+        if as_string:
+            acts = self.actions[:, :, 0].t().cpu().numpy()
+            return [" ".join(str(a) for a in row) for row in acts]
+        return self.actions.squeeze(-1)
+
+    def _episode_action_strings(self):
+        acts = self.actions[:, :, 0].cpu().numpy()
+        masks = self.masks[:, :, 0].cpu().numpy()
+        for b in range(acts.shape[1]):
+            done_steps = [0] + [int(t) for t in (masks[:, b] == 0).nonzero()[0]]
+            for i, t in enumerate(done_steps[:-1]):
+                yield b, " ".join(str(a) for a in acts[t:done_steps[i + 1], b])
+
+    def get_action_complexity(self):
+        total, n = 0, 0
+        for _, s in self._episode_action_strings():
+            total += lempel_ziv_complexity(s)
+            n += 1
+        return total / max(n, 1)
+
+    def get_batched_action_complexity(self):
+        out = torch.zeros(self.actions.shape[1], 1)
+        sums, counts = defaultdict(float), defaultdict(int)
+        for b, s in self._episode_action_strings():
+            sums[b] += lempel_ziv_complexity(s)
+            counts[b] += 1
+        for b in counts:
+            out[b] = sums[b] / counts[b]
+        return out
+
+    # ---- recurrent state helpers ----------------------------------------------------------------
+    def _split_batched_lstm_recurrent_hidden_states(self, hxs):
+        H = self.recurrent_hidden_state_size
+        return hxs[:, :H], hxs[:, H:]
+
+    def get_recurrent_hidden_state(self, step):
+        if self.is_lstm:
+            return self._split_batched_lstm_recurrent_hidden_states(self.recurrent_hidden_states[step])
+        return self.recurrent_hidden_states[step]
+
+    # ---- PPO minibatch generators (reference :400-517) ------------------------------------------
+    def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):
+        T, B = self.rewards.shape[:2]
+        total = T * B
+        if mini_batch_size is None:
+            assert total >= num_mini_batch
+            mini_batch_size = total // num_mini_batch
+        perm = torch.randperm(total)
+        for s in range(0, total, mini_batch_size):
+            idx = perm[s:s + mini_batch_size].to(self.device)
+            flat = lambda x: x.reshape(-1, *x.shape[2:])[idx]
+            obs = {k: flat(v[:-1]) for k, v in self.obs.items()} if self.is_dict_obs else flat(self.obs[:-1])
+            hxs = flat(self.recurrent_hidden_states[:-1])
+            if self.is_lstm:
+                hxs = self._split_batched_lstm_recurrent_hidden_states(hxs)
+            yield (obs, hxs, flat(self.actions), flat(self.value_preds[:-1]), flat(self.returns[:-1]),
+                   flat(self.masks[:-1]), flat(self.action_log_probs),
+                   None if advantages is None else flat(advantages))
+
+    def recurrent_generator(self, advantages, num_mini_batch):
+        B, T = self.num_processes, self.num_steps
+        assert B >= num_mini_batch, (
+            f"PPO requires the number of processes ({B}) to be greater than or equal to "
+            f"the number of PPO mini batches ({num_mini_batch}).")
+        per = B // num_mini_batch
+        perm = torch.randperm(B)                                     # same draw as the reference (:450)
+        for s in range(0, B, per):
+            idx = perm[s:s + per].to(self.device)
+            N = idx.numel()
+            sel = lambda x: x.index_select(1, idx)
+            obs = ({k: sel(v[:-1]) for k, v in self.obs.items()} if self.is_dict_obs else sel(self.obs[:-1]))
+            hxs = self.recurrent_hidden_states[0].index_select(0, idx)
+            if self.is_lstm:
+                hxs = self._split_batched_lstm_recurrent_hidden_states(hxs)
+            yield (_flatten(T, N, obs), hxs, _flatten(T, N, sel(self.actions)),
+                   _flatten(T, N, sel(self.value_preds[:-1])), _flatten(T, N, sel(self.returns[:-1])),
+                   _flatten(T, N, sel(self.masks[:-1])), _flatten(T, N, sel(self.action_log_probs)),
+                   _flatten(T, N, sel(advantages)))
+
+
+def lempel_ziv_complexity(sequence):
+    """Number of phrases in the LZ76 parsing of `sequence` (what the `lempel_ziv_complexity` package
+    used by the reference's action-complexity logging computes, storage.py:21,329-369)."""
+    phrases, i, n = set(), 0, len(sequence)
+    while i < n:
+        j = i + 1
+        while j <= n and sequence[i:j] in phrases:
+            j += 1
+        phrases.add(sequence[i:j])
+        i = j
+    return len(phrases)

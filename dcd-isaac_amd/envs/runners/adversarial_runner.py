@@ -1,0 +1,514 @@
+"""AdversarialRunner — the rollout-and-regret loop (reference: envs/runners/adversarial_runner.py:27-896)
+with the same constructor, `run()` call order, stats keys and `state_dict()` layout, driven through
+the device-level API so that a rollout performs NO host synchronisation per env step:
+
+  reference (per step, :497-588)                       here
+  ------------------------------------------------     ------------------------------------------------
+  agent.act on GPU, action.cpu()  (D2H sync)           agent.act on GPU, action stays on device
+  venv.step_env over pipes to N worker processes       dcd_mg_step: one kernel for all B envs
+  Python loops over infos (episode returns, masks)     kernel writes masks / episode stats to the storage
+  agent.insert: ~12 H2D copies                         kernel writes obs/reward straight into storage[step]
+  _get_rollout_return_stats: Python loop over B        dcd_rollout_return_stats
+  _compute_env_return (regret) on CPU tensors          dcd_env_return
+
+Host decisions that the reference takes inside the step loop (PLR per-episode level re-sampling,
+:551-558) still need the done mask on the host and therefore synchronise once per step in replay
+rollouts; PAIRED / DR / non-replay rollouts are sync-free until the rollout ends.
+"""
+from collections import defaultdict, deque
+
+import numpy as np
+import torch
+
+import dcd_hip
+from dcd_hip import scans
+from level_replay import LevelSampler, LevelStore
+from util import is_discrete_actions
+
+
+class RunningMeanStd:
+    """Parallel-variance running moments (what baselines.common.running_mean_std provides to
+    adversarial_runner.py:84,666-668)."""
+
+    def __init__(self, epsilon=1e-4, shape=()):
+        self.mean = np.zeros(shape, "float64")
+        self.var = np.ones(shape, "float64")
+        self.count = epsilon
+
+    def update(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        b_mean, b_var, b_count = x.mean(axis=0), x.var(axis=0), x.shape[0]
+        delta = b_mean - self.mean
+        tot = self.count + b_count
+        m2 = self.var * self.count + b_var * b_count + np.square(delta) * self.count * b_count / tot
+        self.mean, self.var, self.count = self.mean + delta * b_count / tot, m2 / tot, tot
+
+
+class AdversarialRunner:
+    def __init__(self, args, venv, agent, ued_venv=None, adversary_agent=None, adversary_env=None,
+                 flexible_protagonist=False, train=False, plr_args=None, device="cpu"):
+        self.args = args
+        self.venv = venv
+        self.ued_venv = venv if ued_venv is None else ued_venv
+        self.is_discrete_actions = is_discrete_actions(self.venv)
+        self.is_discrete_adversary_env_actions = is_discrete_actions(self.venv, adversary=True)
+        self.agents = {"agent": agent, "adversary_agent": adversary_agent, "adversary_env": adversary_env}
+        self.agent_rollout_steps = args.num_steps
+        self.adversary_env_rollout_steps = int(self.venv.adversary_observation_space["time_step"].high[0])
+        self.is_dr = args.ued_algo == "domain_randomization"
+        self.is_training_env = args.ued_algo in ["paired", "flexible_paired", "minimax"]
+        self.is_paired = args.ued_algo in ["paired", "flexible_paired"]
+        self.requires_batched_vloss = args.use_editor and args.base_levels == "easy"
+        if args.ued_algo == "alp_gmm":
+            raise NotImplementedError("ALP-GMM only drives BipedalWalker in the reference (SURVEY §2 #21)")
+        if args.adv_normalize_returns:
+            self.env_return_rms = RunningMeanStd(shape=())
+        self.device = torch.device(device)
+        self.train() if train else self.eval()
+        self.reset()
+
+        self.level_store = None
+        self.level_samplers = {}
+        self.current_level_seeds = None
+        self.weighted_num_edits = 0
+        self.latest_env_stats = defaultdict(float)
+        if plr_args:
+            if self.is_paired:
+                if not args.protagonist_plr and not args.antagonist_plr:
+                    self.level_samplers.update({"agent": LevelSampler(**plr_args),
+                                                "adversary_agent": LevelSampler(**plr_args)})
+                elif args.protagonist_plr:
+                    self.level_samplers["agent"] = LevelSampler(**plr_args)
+                elif args.antagonist_plr:
+                    self.level_samplers["adversary_agent"] = LevelSampler(**plr_args)
+            else:
+                self.level_samplers["agent"] = LevelSampler(**plr_args)
+            if self.use_byte_encoding:
+                example = self.ued_venv.get_encodings()[0]
+                self.level_store = LevelStore(data_info={"numpy": True, "dtype": example.dtype, "shape": example.shape})
+            else:
+                self.level_store = LevelStore()
+            self.current_level_seeds = [-1 for _ in range(args.num_processes)]
+            self._default_level_sampler = self.all_level_samplers[0]
+            self.use_editor = args.use_editor
+            self.edit_prob = args.level_editor_prob
+            self.base_levels = args.base_levels
+        else:
+            self.use_editor = False
+            self.edit_prob = 0
+            self.base_levels = None
+        B = args.num_processes
+        self._done_buf = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        self._seeds_dev = torch.full((B, 1), -1, dtype=torch.int32, device=self.device)
+
+    # ---- bookkeeping ---------------------------------------------------------------------------
+    @property
+    def use_byte_encoding(self):
+        env_name = self.args.env_name
+        return bool(self.args.use_editor or env_name.startswith("BipedalWalker")
+                    or (env_name.startswith("MultiGrid") and self.args.use_reset_random_dr))
+
+    def reset(self):
+        self.num_updates = 0
+        self.total_num_edits = 0
+        self.total_episodes_collected = 0
+        self.total_seeds_collected = 0
+        self.student_grad_updates = 0
+        self.sampled_level_info = None
+        self.agent_returns = deque(maxlen=10)
+        self.adversary_agent_returns = deque(maxlen=10)
+
+    def train(self):
+        self.is_training = True
+        for a in self.agents.values():
+            if a:
+                a.train()
+
+    def eval(self):
+        self.is_training = False
+        for a in self.agents.values():
+            if a:
+                a.eval()
+
+    def state_dict(self):
+        agent_sd, optim_sd = {}, {}
+        for k, a in self.agents.items():
+            if a:
+                agent_sd[k] = a.algo.actor_critic.state_dict()
+                optim_sd[k] = a.algo.optimizer.state_dict()
+        return {"agent_state_dict": agent_sd, "optimizer_state_dict": optim_sd, "agent_returns": self.agent_returns,
+                "adversary_agent_returns": self.adversary_agent_returns, "num_updates": self.num_updates,
+                "total_episodes_collected": self.total_episodes_collected,
+                "total_seeds_collected": self.total_seeds_collected, "total_num_edits": self.total_num_edits,
+                "student_grad_updates": self.student_grad_updates, "latest_env_stats": self.latest_env_stats,
+                "level_store": self.level_store, "level_samplers": self.level_samplers}
+
+    def load_state_dict(self, sd):
+        for k, state in sd.get("agent_state_dict").items():
+            self.agents[k].algo.actor_critic.load_state_dict(state)
+        for k, state in sd.get("optimizer_state_dict").items():
+            self.agents[k].algo.optimizer.load_state_dict(state)
+        for key in ("agent_returns", "adversary_agent_returns", "num_updates", "total_episodes_collected",
+                    "total_seeds_collected", "total_num_edits", "student_grad_updates", "latest_env_stats",
+                    "level_store", "level_samplers"):
+            setattr(self, key, sd.get(key))
+        if self.args.use_plr:
+            self._default_level_sampler = self.all_level_samplers[0]
+            if self.use_editor:
+                self.weighted_num_edits = self._get_weighted_num_edits()
+
+    # ---- stats ---------------------------------------------------------------------------------
+    def _rollout_return_stats(self, storage):
+        """Per-env mean / max of the episode returns of this rollout (:257-271), on device; plus the
+        last <=10 returns in the reference's append order for the running mean (:845-853)."""
+        mean, mx, n = scans.rollout_return_stats(storage.ep_ret, storage.ep_info)
+        info = storage.ep_info.t().cpu().numpy()                     # [B,T]
+        rets = storage.ep_ret.t().cpu().numpy()
+        b_idx, t_idx = np.nonzero(info & dcd_hip.INFO_EPISODE)       # env-major, time ascending
+        tail = []
+        if len(b_idx):
+            # reference order: for b in envs: for r in reversed(returns[b]); keep the last 10 appended
+            order = np.lexsort((-t_idx, b_idx))
+            tail = rets[b_idx[order], t_idx[order]][-10:].tolist()
+        return {"mean_return": mean, "max_return": mx, "num_episodes": n, "returns_tail": tail,
+                "total_episodes": int(len(b_idx))}
+
+    def _get_env_stats_multigrid(self, agent_info, adversary_agent_info):
+        num_blocks = np.mean(agent_info.get("num_blocks", self.venv.get_num_blocks()))
+        passable_ratio = np.mean(agent_info.get("passable_ratio", self.venv.get_passable()))
+        spl = agent_info.get("shortest_path_lengths", self.venv.get_shortest_path_length())
+        solved_idx = agent_info.get("solved_idx", None)
+        if solved_idx is None:
+            solved_idx = (agent_info["max_return"] > 0).cpu().numpy().reshape(-1)
+        solved = np.array(spl)[solved_idx]
+        return {"num_blocks": num_blocks, "passable_ratio": passable_ratio, "shortest_path_length": np.mean(spl),
+                "solved_path_length": np.mean(solved) if len(solved) > 0 else 0}
+
+    def _get_plr_buffer_stats(self):
+        stats = {}
+        for k, s in self.level_samplers.items():
+            stats[k + "_plr_passable_mass"] = s.solvable_mass
+            stats[k + "_plr_max_score"] = s.max_score
+            stats[k + "_plr_weighted_num_edits"] = self.weighted_num_edits
+        return stats
+
+    def _get_env_stats(self, agent_info, adversary_agent_info, log_replay_complexity=False):
+        if not self.args.env_name.startswith("MultiGrid"):
+            raise ValueError(f"Unsupported environment, {self.args.env_name}")
+        stats = self._get_env_stats_multigrid(agent_info, adversary_agent_info)
+        out = {}
+        for k, v in stats.items():
+            out["plr_" + k] = v if log_replay_complexity else None
+            out[k] = v if not log_replay_complexity else None
+        return out
+
+    # ---- PLR plumbing -----------------------------------------------------------------------------
+    def _get_active_levels(self):
+        assert self.args.use_plr, "Only call _get_active_levels when using PLR."
+        if self.use_byte_encoding:
+            return [x.tobytes() for x in self.ued_venv.get_encodings()]
+        return self.agents["adversary_env"].storage.get_action_traj(as_string=True)
+
+    def _get_level_sampler(self, name):
+        other = "agent" if name == "adversary_agent" else "adversary_agent"
+        sampler = self.level_samplers.get(name) or self.level_samplers.get(other)
+        return sampler, name in self.level_samplers
+
+    @property
+    def all_level_samplers(self):
+        return [v for v in self.level_samplers.values() if v is not None]
+
+    def _should_edit_level(self):
+        return bool(self.use_editor and np.random.rand() < self.edit_prob)
+
+    def _update_plr_with_current_unseen_levels(self, parent_seeds=None):
+        levels = self._get_active_levels()
+        self.current_level_seeds = self.level_store.insert(levels, parent_seeds=parent_seeds)
+        passable = self.venv.get_passable() if (self.args.log_plr_buffer_stats or self.args.reject_unsolvable_seeds) else None
+        seeds, solvable = self.current_level_seeds, passable
+        if self.args.reject_unsolvable_seeds:
+            solvable = np.array(solvable, dtype=bool)
+            seeds = np.array(seeds, dtype=int)[solvable]
+            solvable = solvable[solvable]
+        for sampler in self.all_level_samplers:
+            sampler.observe_external_unseen_sample(seeds, solvable)
+
+    def _reconcile_level_store_and_samplers(self):
+        all_seeds = set()
+        for sampler in self.all_level_samplers:
+            all_seeds.update([x for x in sampler.seeds if x >= 0])
+        self.level_store.reconcile_seeds(all_seeds)
+
+    def _get_weighted_num_edits(self):
+        sampler = self.all_level_samplers[0]
+        n = np.zeros(sampler.seed_buffer_size)
+        for idx, value in enumerate(self.level_store.seed2parent.values()):
+            n[idx] = len(value)
+        return np.dot(sampler.sample_weights(), n)
+
+    def _sample_replay_decision(self):
+        return self._default_level_sampler.sample_replay_decision()
+
+    # ---- rollouts --------------------------------------------------------------------------------
+    def _teacher_rollout(self, agent, num_steps):
+        """Constructive teacher episode (:481, :497-592 with is_env=True)."""
+        st, venv, B = agent.storage, self.ued_venv, self.args.num_processes
+        venv.reset_device(st.adversary_obs_out(0))
+        for step in range(num_steps):
+            with torch.no_grad():
+                value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step),
+                                                         st.masks[step])
+                log_prob = log_dist.gather(-1, action) if self.is_discrete_adversary_env_actions else log_dist
+            st.insert_policy(hxs, action, log_prob, log_dist, value)
+            out = st.adversary_obs_out(step + 1)
+            out["done"] = self._done_buf
+            venv.step_adversary_device(action.view(-1), out)
+            st.rewards[step].zero_()
+            st.masks[step + 1].copy_((1 - self._done_buf.float()).view(B, 1))
+            st.bad_masks[step + 1].fill_(1.0)
+            st.cliffhanger_masks[step + 1].fill_(1.0)
+            st.advance()
+        venv.raise_errors()
+
+    def _resample_finished_levels(self, st, step, level_sampler, rollout_info):
+        """PLR replay rollouts: every env that finished an episode gets a new replay level
+        (:551-558).  Needs the done mask on the host: one synchronisation per step."""
+        finished = (st.ep_info[step] & dcd_hip.INFO_EPISODE).nonzero().flatten()
+        if finished.numel() == 0:
+            return
+        idx = finished.cpu().tolist()
+        seeds = [level_sampler.sample_replay_level() for _ in idx]
+        levels = [self.level_store.get_level(s) for s in seeds]
+        kind, a, b = self.venv._levels_to_device(levels)
+        idx_dev = finished.to(torch.int32)
+        out = self.venv.engine.student_buffers(len(idx), u8=False)
+        if kind == "enc":
+            self.venv.engine.reset_to_encoding(a, idx_dev, out)
+        else:
+            self.venv.engine.reset_to_actions(a, b, idx_dev, out)
+        st.obs["image"][step + 1][finished] = out["image_f32"]
+        st.obs["direction"][step + 1][finished] = out["dir_f32"]
+        for i, s in zip(idx, seeds):
+            self._next_level_seeds[i] = s
+            rollout_info["solved_idx"][i] = True
+
+    def _student_rollout(self, agent, num_steps, level_replay, level_sampler, rollout_info):
+        args, st, venv = self.args, agent.storage, self.venv
+        reset_random = self.is_dr and not args.use_plr
+        venv.reset_agent_device(st.student_obs_out(0))
+        track_seeds = level_sampler is not None
+        if track_seeds:
+            self._seeds_dev.copy_(torch.tensor(self.current_level_seeds, dtype=torch.int32).view(-1, 1))
+        for step in range(num_steps):
+            with torch.no_grad():
+                value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step),
+                                                         st.masks[step])
+                log_prob = log_dist.gather(-1, action) if self.is_discrete_actions else log_dist
+            st.insert_policy(hxs, action, log_prob, log_dist, value, self._seeds_dev if track_seeds else None)
+            last = step >= num_steps - 1
+            venv.step_env_device(action.view(-1), st.step_out(step), reset_random=reset_random,
+                                 last_step=last and st.use_proper_time_limits)
+            if last and not st.use_proper_time_limits:
+                st.masks[step + 1].zero_()                              # done forced on the last step (:530)
+            if args.clip_reward:
+                st.rewards[step].clamp_(-args.clip_reward, args.clip_reward)
+            if level_sampler is not None and level_replay:
+                self._next_level_seeds = list(self.current_level_seeds)
+                self._resample_finished_levels(st, step, level_sampler, rollout_info)
+                self.current_level_seeds = self._next_level_seeds
+                self._seeds_dev.copy_(torch.tensor(self.current_level_seeds, dtype=torch.int32).view(-1, 1))
+            st.advance()
+        venv.raise_errors()
+
+    def agent_rollout(self, agent, num_steps, update=False, is_env=False, level_replay=False, level_sampler=None,
+                      update_level_sampler=False, discard_grad=False, edit_level=False, num_edits=0, fixed_seeds=None):
+        args = self.args
+        B = args.num_processes
+        if is_env:
+            if edit_level:
+                levels = [self.level_store.get_level(seed) for seed in fixed_seeds]
+                self.ued_venv.reset_to_level_batch(levels)
+                self.ued_venv.mutate_level(num_edits=num_edits)
+                self._update_plr_with_current_unseen_levels(parent_seeds=fixed_seeds)
+                return
+            if level_replay:
+                self.current_level_seeds = [level_sampler.sample_replay_level() for _ in range(B)]
+                levels = [self.level_store.get_level(seed) for seed in self.current_level_seeds]
+                self.ued_venv.reset_to_level_batch(levels)
+                return self.current_level_seeds
+            if self.is_dr and not args.use_plr:
+                self.ued_venv.reset_random_device({})
+                self.total_seeds_collected += B
+                return
+            if self.is_dr and args.use_plr and args.use_reset_random_dr:
+                self.ued_venv.reset_random_device({})
+                self._update_plr_with_current_unseen_levels(parent_seeds=fixed_seeds)
+                self.total_seeds_collected += B
+                return
+            self.total_seeds_collected += B
+            self._teacher_rollout(agent, num_steps)
+            if args.use_plr and not level_replay:
+                self._update_plr_with_current_unseen_levels()
+            return {}
+
+        rollout_info = {}
+        if level_sampler and level_replay:
+            rollout_info["solved_idx"] = np.zeros(B, dtype=bool)
+        self._student_rollout(agent, num_steps, level_replay, level_sampler, rollout_info)
+        stats = self._rollout_return_stats(agent.storage)
+        rollout_info.update(stats)
+        self.total_episodes_collected += stats["total_episodes"]
+        if self.is_dr and not args.use_plr:
+            self.total_seeds_collected += stats["total_episodes"]
+        if update:
+            st = agent.storage
+            with torch.no_grad():
+                next_value = agent.get_value(st.get_obs(-1), st.get_recurrent_hidden_state(-1), st.masks[-1]).detach()
+            st.compute_returns(next_value, args.use_gae, args.gamma, args.gae_lambda)
+            if self.requires_batched_vloss:
+                clipped = not args.adv_use_popart and not args.adv_normalize_returns
+                rollout_info["batched_value_loss"] = st.get_batched_value_loss(
+                    signed=False, positive_only=False, clipped=clipped, batched=True)
+            if level_sampler and update_level_sampler:
+                level_sampler.update_with_rollouts(st)
+            value_loss, action_loss, dist_entropy, info = agent.update(discard_grad=discard_grad)
+            if level_sampler and update_level_sampler:
+                level_sampler.after_update()
+            rollout_info.update({"value_loss": value_loss, "action_loss": action_loss, "dist_entropy": dist_entropy,
+                                 "update_info": info})
+            if args.log_action_complexity:
+                rollout_info["action_complexity"] = st.get_action_complexity()
+        return rollout_info
+
+    def _compute_env_return(self, agent_info, adversary_agent_info):
+        """Teacher's final return: the regret (:637-674), on device."""
+        args = self.args
+        mode = {"paired": 0, "flexible_paired": 1, "minimax": 2}.get(args.ued_algo)
+        if mode is None:
+            env_return = torch.zeros_like(agent_info["mean_return"])
+        else:
+            adv = adversary_agent_info if self.is_paired else agent_info
+            env_return = scans.env_return(agent_info["mean_return"], agent_info["max_return"], adv["mean_return"],
+                                          adv["max_return"], mode=mode)
+        if args.adv_normalize_returns:
+            self.env_return_rms.update(env_return.flatten().cpu().numpy())
+            env_return = env_return / float(np.sqrt(self.env_return_rms.var + 1e-8))
+        if args.adv_clip_reward is not None:
+            env_return = env_return.clamp(-args.adv_clip_reward, args.adv_clip_reward)
+        return env_return
+
+    # ---- one update ------------------------------------------------------------------------------
+    def run(self):
+        args = self.args
+        adversary_env, agent, adversary_agent = (self.agents[k] for k in ("adversary_env", "agent", "adversary_agent"))
+        level_replay = bool(args.use_plr and self.is_training and self._sample_replay_decision())
+        student_discard_grad = bool(args.use_plr and (not level_replay)
+                                    and vars(args).get("no_exploratory_grad_updates", False))
+        if self.is_training and not student_discard_grad:
+            self.student_grad_updates += 1
+
+        env_info = self.agent_rollout(agent=adversary_env, num_steps=self.adversary_env_rollout_steps, update=False,
+                                      is_env=True, level_replay=level_replay,
+                                      level_sampler=self._get_level_sampler("agent")[0], update_level_sampler=False)
+        level_sampler, updateable = self._get_level_sampler("agent")
+        agent_info = self.agent_rollout(agent=agent, num_steps=self.agent_rollout_steps, update=self.is_training,
+                                        level_replay=level_replay, level_sampler=level_sampler,
+                                        update_level_sampler=updateable, discard_grad=student_discard_grad)
+        if level_replay and self.is_paired and (args.protagonist_plr == args.antagonist_plr):
+            self.agent_rollout(agent=adversary_env, num_steps=self.adversary_env_rollout_steps, update=False,
+                               is_env=True, level_replay=level_replay,
+                               level_sampler=self._get_level_sampler("adversary_agent")[0], update_level_sampler=False)
+        adversary_agent_info = defaultdict(float)
+        if self.is_paired:
+            level_sampler, updateable = self._get_level_sampler("adversary_agent")
+            adversary_agent_info = self.agent_rollout(agent=adversary_agent, num_steps=self.agent_rollout_steps,
+                                                      update=self.is_training, level_replay=level_replay,
+                                                      level_sampler=level_sampler, update_level_sampler=updateable,
+                                                      discard_grad=student_discard_grad)
+
+        edit_level = self._should_edit_level() and level_replay
+        if level_replay:
+            sampled_level_info = {"level_replay": True,
+                                  "num_edits": [len(self.level_store.seed2parent[x]) + 1 for x in env_info]}
+        else:
+            sampled_level_info = {"level_replay": False, "num_edits": [0 for _ in range(args.num_processes)]}
+
+        if level_replay and edit_level:                                   # ---- ACCEL (:758-794)
+            if self.base_levels == "batch":
+                fixed_seeds = env_info
+            elif self.base_levels == "easy":
+                ease = (agent_info["mean_return"] - agent_info["batched_value_loss"]).detach().cpu().numpy().flatten()
+                if args.num_processes >= 4:
+                    easy = list(np.argsort(ease)[:4])
+                    fixed_seeds = [env_info[int(x)] for x in easy] * int(args.num_processes / 4)
+                else:
+                    fixed_seeds = [env_info[int(np.argmax(ease))]] * args.num_processes
+            level_sampler, updateable = self._get_level_sampler("agent")
+            self.agent_rollout(agent=None, num_steps=None, is_env=True, edit_level=True, num_edits=args.num_edits,
+                               fixed_seeds=fixed_seeds)
+            self.total_num_edits += 1
+            sampled_level_info["num_edits"] = [x + 1 for x in sampled_level_info["num_edits"]]
+            self.agent_rollout(agent=agent, num_steps=self.agent_rollout_steps, update=self.is_training,
+                               level_replay=False, level_sampler=level_sampler, update_level_sampler=updateable,
+                               discard_grad=True)
+
+        if args.use_plr:
+            self._reconcile_level_store_and_samplers()
+            if self.use_editor:
+                self.weighted_num_edits = self._get_weighted_num_edits()
+
+        env_return = self._compute_env_return(agent_info, adversary_agent_info)
+        adversary_env_info = defaultdict(float)
+        if self.is_training and self.is_training_env:
+            st = adversary_env.storage
+            with torch.no_grad():
+                next_value = adversary_env.get_value(st.get_obs(-1), st.get_recurrent_hidden_state(-1),
+                                                     st.masks[-1]).detach()
+            st.replace_final_return(env_return)
+            st.compute_returns(next_value, args.use_gae, args.gamma, args.gae_lambda)
+            v, a, e, info = adversary_env.update()
+            adversary_env_info.update({"action_loss": a, "value_loss": v, "dist_entropy": e, "update_info": info})
+        if self.is_training:
+            self.num_updates += 1
+
+        # ---- logging (:825-896) ----------------------------------------------------------------
+        log_replay_complexity = level_replay and args.log_replay_complexity
+        if (not level_replay) or log_replay_complexity:
+            stats = self._get_env_stats(agent_info, adversary_agent_info, log_replay_complexity=log_replay_complexity)
+            stats.update({"mean_env_return": env_return.mean().item(),
+                          "adversary_env_pg_loss": adversary_env_info["action_loss"],
+                          "adversary_env_value_loss": adversary_env_info["value_loss"],
+                          "adversary_env_dist_entropy": adversary_env_info["dist_entropy"]})
+            if args.use_plr:
+                self.latest_env_stats.update(stats)
+        else:
+            stats = self.latest_env_stats.copy()
+        if args.use_plr and args.log_plr_buffer_stats:
+            stats.update(self._get_plr_buffer_stats())
+        self.agent_returns.extend(agent_info["returns_tail"])
+        mean_agent_return = np.mean(self.agent_returns) if len(self.agent_returns) > 0 else 0
+        mean_adversary_agent_return = 0
+        if self.is_paired:
+            self.adversary_agent_returns.extend(adversary_agent_info["returns_tail"])
+            if len(self.adversary_agent_returns) > 0:
+                mean_adversary_agent_return = np.mean(self.adversary_agent_returns)
+        self.sampled_level_info = sampled_level_info
+        stats.update({
+            "steps": (self.num_updates + self.total_num_edits) * args.num_processes * args.num_steps,
+            "total_episodes": self.total_episodes_collected, "total_seeds": self.total_seeds_collected,
+            "total_student_grad_updates": self.student_grad_updates, "mean_agent_return": mean_agent_return,
+            "agent_value_loss": agent_info["value_loss"] if "value_loss" in agent_info else 0.0,
+            "agent_pg_loss": agent_info.get("action_loss", 0.0), "agent_dist_entropy": agent_info.get("dist_entropy", 0.0),
+            "mean_adversary_agent_return": mean_adversary_agent_return,
+            "adversary_value_loss": adversary_agent_info["value_loss"],
+            "adversary_pg_loss": adversary_agent_info["action_loss"],
+            "adversary_dist_entropy": adversary_agent_info["dist_entropy"]})
+        if args.log_grad_norm:
+            stats.update({
+                "agent_grad_norm": np.mean(agent_info["update_info"]["grad_norms"]),
+                "adversary_grad_norm": np.mean(adversary_agent_info["update_info"]["grad_norms"]) if self.is_paired else 0,
+                "adversary_env_grad_norm": np.mean(adversary_env_info["update_info"]["grad_norms"]) if self.is_training_env else 0})
+        if args.log_action_complexity:
+            stats.update({"agent_action_complexity": agent_info["action_complexity"],
+                          "adversary_action_complexity": adversary_agent_info["action_complexity"]})
+        return stats

@@ -1,0 +1,449 @@
+"""LevelSampler — Prioritized Level Replay bookkeeping with the reference's constructor, attributes
+and method set (reference: level_replay/level_sampler.py:19-800).
+
+Split of work:
+  * segmentation of the rollout into per-(actor, episode) records and the per-record score
+    (mean/max of the strategy's per-step quantity) run on the GPU: dcd_hip.scans.EpisodeScorer
+    (kernels seg_count / seg_scan / seg_score in csrc/scan_kernels.hip), emitted in the reference's
+    iteration order (actor-major, then time; :497-578);
+  * the order-dependent bookkeeping (partial-score merging, exponential averaging, staging ->
+    working buffer insertion, staleness, sampling weights) stays on the host in float64 numpy
+    exactly as in the reference, consuming the records sequentially.  `after_update`, an
+    O(num_actors x buffer) pure-Python double loop in the reference (:585-588), visits only the
+    non-zero partial scores, in the same order.
+
+`update_with_records` is the host half on its own (used by the CPU tests with oracle records and by
+the multi-GPU path, where rank 0 consumes the all-gathered records of every rank).
+"""
+from collections import defaultdict
+
+import numpy as np
+
+INT32_MAX = 2147483647
+
+# strategy -> (dcd_episode_scores code, needs returns/values)
+_GPU_STRATEGY = {"uniform": 7, "policy_entropy": 3, "least_confidence": 4, "min_margin": 5, "gae": 2,
+                 "value_l1": 0, "signed_value_loss": 2, "positive_value_loss": 1,
+                 "grounded_signed_value_loss": 8, "grounded_positive_value_loss": 8, "one_step_td_error": 6}
+_VALUE_STRATEGIES = ("gae", "value_l1", "signed_value_loss", "positive_value_loss", "grounded_signed_value_loss",
+                     "grounded_positive_value_loss", "one_step_td_error", "alt_advantage_abs", "tscl_window")
+
+
+class LevelSampler:
+    def __init__(self, seeds, obs_space, action_space, num_actors=1, strategy="random", max_score_coef=0.0,
+                 replay_schedule="fixed", score_transform="power", temperature=1.0, eps=0.05, rho=1.0,
+                 replay_prob=0.95, alpha=1.0, staleness_coef=0, staleness_transform="power",
+                 staleness_temperature=1.0, sample_full_distribution=False, seed_buffer_size=0,
+                 seed_buffer_priority="replay_support", use_dense_rewards=False, tscl_window_size=0, gamma=0.999):
+        if strategy in ("tscl_window", "alt_advantage_abs"):
+            raise NotImplementedError(f"strategy '{strategy}' is outside the MultiGrid configs and not supported")
+        self.obs_space, self.action_space = obs_space, action_space
+        self.num_actors = num_actors
+        self.strategy = strategy
+        self.max_score_coef = max_score_coef
+        self.replay_schedule = replay_schedule
+        self.score_transform = score_transform
+        self.temperature = temperature
+        self.eps = eps
+        self.rho = rho
+        self.replay_prob = replay_prob
+        self.alpha = alpha
+        self.staleness_coef = staleness_coef
+        self.staleness_transform = staleness_transform
+        self.staleness_temperature = staleness_temperature
+        self.gamma = gamma
+        self.use_dense_rewards = use_dense_rewards
+
+        self.seed_buffer_size = seed_buffer_size if not seeds else len(seeds)
+        N = self.seed_buffer_size
+        self._init_seed_index(seeds)
+        self.unseen_seed_weights = np.ones(N, dtype=np.float64)
+        self.seed_scores = np.zeros(N, dtype=np.float64)
+        self.partial_seed_scores = np.zeros((num_actors, N), dtype=np.float64)
+        self.partial_seed_max_scores = np.full((num_actors, N), -np.inf, dtype=np.float64)
+        self.partial_seed_steps = np.zeros((num_actors, N), dtype=np.int32)
+        self.seed_staleness = np.zeros(N, dtype=np.float64)
+        self.running_sample_count = 0
+        self.next_seed_index = 0
+        self.track_solvable = False
+        self.grounded_values = np.full(N, -np.inf, dtype=np.float64) if strategy.startswith("grounded") else None
+
+        self.sample_full_distribution = sample_full_distribution
+        if sample_full_distribution:
+            self.seed2actor = defaultdict(set)
+            self.working_seed_buffer_size = 0
+            self.seed_buffer_priority = seed_buffer_priority
+            self.staging_seed_set = set()
+            self.working_seed_set = set()
+            self.seed2timestamp_buffer = {}
+            self.partial_seed_scores_buffer = [{} for _ in range(num_actors)]
+            self.partial_seed_max_scores_buffer = [{} for _ in range(num_actors)]
+            self.partial_seed_steps_buffer = [{} for _ in range(num_actors)]
+        self._scorer = None
+
+    # ---- seed index ---------------------------------------------------------------------------
+    def seed_range(self):
+        if not self.sample_full_distribution:
+            return int(min(self.seeds)), int(max(self.seeds))
+        return 0, INT32_MAX
+
+    def _init_seed_index(self, seeds):
+        if seeds:
+            self.seeds = np.array(seeds, dtype=np.int64)
+            self.seed2index = {seed: i for i, seed in enumerate(seeds)}
+        else:
+            self.seeds = np.zeros(self.seed_buffer_size, dtype=np.int64) - 1
+            self.seed2index = {}
+
+    def _init_solvable_tracking(self):
+        self.track_solvable = True
+        self.staging_seed2solvable = {}
+        self.seed_solvable = np.ones(self.seed_buffer_size, dtype=bool)
+
+    @property
+    def _proportion_filled(self):
+        if self.sample_full_distribution:
+            return self.working_seed_buffer_size / self.seed_buffer_size
+        num_unseen = (self.unseen_seed_weights > 0).sum()
+        return (len(self.seeds) - num_unseen) / len(self.seeds)
+
+    @property
+    def requires_value_buffers(self):
+        return self.strategy in _VALUE_STRATEGIES
+
+    @property
+    def _has_working_seed_buffer(self):
+        return not self.sample_full_distribution or self.seed_buffer_size > 0
+
+    @property
+    def is_warm(self):
+        return self._proportion_filled >= self.rho
+
+    # ---- score updates (reference :185-273) ---------------------------------------------------
+    def update_seed_score(self, actor_index, seed, score, max_score, num_steps):
+        if self.sample_full_distribution and seed in self.staging_seed_set:
+            return self._partial_update_seed_score_buffer(actor_index, seed, score, num_steps, done=True)
+        return self._partial_update_seed_score(actor_index, seed, score, max_score, num_steps, done=True)
+
+    def _partial_update_seed_score(self, actor_index, seed, score, max_score, num_steps, done=False):
+        seed_idx = self.seed2index.get(seed, -1)
+        if seed_idx < 0:
+            return 0, None
+        partial_score = self.partial_seed_scores[actor_index][seed_idx]
+        partial_max = self.partial_seed_max_scores[actor_index][seed_idx]
+        partial_steps = self.partial_seed_steps[actor_index][seed_idx]
+        running = partial_steps + num_steps
+        merged = partial_score + (score - partial_score) * num_steps / float(running)
+        merged_max = max(partial_max, max_score)
+        if done:
+            self.partial_seed_scores[actor_index][seed_idx] = 0.0
+            self.partial_seed_max_scores[actor_index][seed_idx] = float("-inf")
+            self.partial_seed_steps[actor_index][seed_idx] = 0
+            self.unseen_seed_weights[seed_idx] = 0.0
+            old = self.seed_scores[seed_idx]
+            total = self.max_score_coef * merged_max + (1 - self.max_score_coef) * merged
+            self.seed_scores[seed_idx] = (1 - self.alpha) * old + self.alpha * total
+        else:
+            self.partial_seed_scores[actor_index][seed_idx] = merged
+            self.partial_seed_max_scores[actor_index][seed_idx] = merged_max
+            self.partial_seed_steps[actor_index][seed_idx] = running
+        return merged, seed_idx
+
+    @property
+    def _next_buffer_index(self):
+        if self._proportion_filled < 1.0:
+            return self.working_seed_buffer_size
+        if self.seed_buffer_priority == "replay_support":
+            return self.sample_weights().argmin()
+        return self.seed_scores.argmin()
+
+    def _partial_update_seed_score_buffer(self, actor_index, seed, score, num_steps, done=False):
+        seed_idx = -1
+        self.seed2actor[seed].add(actor_index)
+        partial_score = self.partial_seed_scores_buffer[actor_index].get(seed, 0)
+        partial_steps = self.partial_seed_steps_buffer[actor_index].get(seed, 0)
+        running = partial_steps + num_steps
+        merged = partial_score + (score - partial_score) * num_steps / float(running)
+        if done:
+            seed_idx = self._next_buffer_index
+            if self.seed_scores[seed_idx] <= merged or self.unseen_seed_weights[seed_idx] > 0:
+                self.unseen_seed_weights[seed_idx] = 0.0
+                self.working_seed_set.discard(self.seeds[seed_idx])
+                self.working_seed_set.add(seed)
+                self.seeds[seed_idx] = seed
+                self.seed2index[seed] = seed_idx
+                self.seed_scores[seed_idx] = merged
+                self.partial_seed_scores[:, seed_idx] = 0.0
+                self.partial_seed_steps[:, seed_idx] = 0
+                self.seed_staleness[seed_idx] = self.running_sample_count - self.seed2timestamp_buffer[seed]
+                self.working_seed_buffer_size = min(self.working_seed_buffer_size + 1, self.seed_buffer_size)
+                if self.track_solvable:
+                    self.seed_solvable[seed_idx] = self.staging_seed2solvable.get(seed, True)
+            else:
+                seed_idx = None
+            for a in self.seed2actor[seed]:
+                self.partial_seed_scores_buffer[a].pop(seed, None)
+                self.partial_seed_steps_buffer[a].pop(seed, None)
+            del self.seed2timestamp_buffer[seed]
+            del self.seed2actor[seed]
+            self.staging_seed_set.remove(seed)
+            if self.track_solvable:
+                del self.staging_seed2solvable[seed]
+        else:
+            self.partial_seed_scores_buffer[actor_index][seed] = merged
+            self.partial_seed_steps_buffer[actor_index][seed] = running
+        return merged, seed_idx
+
+    # ---- rollouts -> records -> scores ----------------------------------------------------------
+    def update_with_rollouts(self, rollouts):
+        """GPU segmentation + scoring of `rollouts` (a RolloutStorage on a HIP device), then the
+        sequential host update (reference :149-183, :486-578)."""
+        if self.strategy in ("random", "off") or not self._has_working_seed_buffer:
+            return
+        if self.strategy not in _GPU_STRATEGY:
+            raise ValueError(f"Unsupported strategy, {self.strategy}")
+        recs = self.score_rollouts(rollouts)
+        values = None
+        if self.grounded_values is not None:
+            values = rollouts.value_preds[:, :, 0].float().cpu().numpy()
+        self.update_with_records(recs, values)
+
+    def score_rollouts(self, rollouts):
+        """Launches the episode scorer on rollouts' device and reads the records back (synchronises)."""
+        from dcd_hip import scans
+        T, B = rollouts.action_log_dist.shape[:2]
+        if self._scorer is None or (self._scorer.T, self._scorer.B) != (T, B) or self._scorer.device != rollouts.device:
+            self._scorer = scans.EpisodeScorer(T, B, rollouts.device)
+        self._scorer.launch(rollouts.returns, rollouts.value_preds, rollouts.rewards, rollouts.masks,
+                            rollouts.cliffhanger_masks, rollouts.level_seeds, rollouts.action_log_dist,
+                            _GPU_STRATEGY[self.strategy], self.gamma)
+        return self._scorer.records()
+
+    def _grounded_score(self, rec, grounded_value, values, actor, seed, done, positive):
+        """_average_grounded_{signed,positive}_value_loss (:351-424) for one record.  `actor` is the
+        global actor index (sampler bookkeeping); `values` is indexed by the record's own actor."""
+        seed_idx = self.seed2index.get(seed, None)
+        if self.sample_full_distribution and seed in self.partial_seed_steps_buffer[actor]:
+            partial_steps = self.partial_seed_steps_buffer[actor][seed]
+        elif seed_idx is not None:
+            partial_steps = self.partial_seed_steps[actor][seed_idx]
+        else:
+            partial_steps = 0
+        new_steps = int(rec["num_steps"])
+        total_steps = partial_steps + new_steps
+        if not (done and grounded_value is not None):
+            return 0, 0
+        s = int(rec["start_t"])
+        col = int(rec["actor"])
+        v = values[s:s + 1, col] if self.use_dense_rewards else values[s:s + new_steps, col]
+        adv = np.float32(grounded_value) - v.astype(np.float32)
+        if positive:
+            adv = np.maximum(adv, np.float32(0))
+        mean = float(np.float32(adv.astype(np.float64).mean()))
+        return (total_steps / new_steps) * mean, float(adv.max())
+
+    def update_with_records(self, recs, values=None, actor_offset=0):
+        """Host half of _update_with_rollouts: consume records in order.  `values` ([T+1,B] float32
+        numpy) is required for grounded_* strategies; actor_offset shifts local actor indices of a
+        remote rank into the global actor space."""
+        grounded = self.grounded_values is not None
+        positive = self.strategy == "grounded_positive_value_loss"
+        for rec in recs:
+            actor = int(rec["actor"]) + actor_offset
+            seed = int(rec["seed"])
+            flags = int(rec["flags"])
+            num_steps = int(rec["num_steps"])
+            if flags & 1:                                            # full episode ending in a done step
+                if flags & 2:                                        # cliffhanger: no score update (:528)
+                    continue
+                grounded_value = None
+                if grounded:
+                    seed_idx = self.seed2index.get(seed, None)
+                    gv = float(rec["reward_sum"])
+                    grounded_value = max(self.grounded_values[seed_idx], gv) if seed_idx is not None else gv
+                    score, max_score = self._grounded_score(rec, grounded_value, values, actor, seed, True, positive)
+                else:
+                    score, max_score = float(rec["mean_score"]), float(rec["max_score"])
+                _, seed_idx = self.update_seed_score(actor, seed, score, max_score, num_steps)
+                if seed_idx is not None and grounded and grounded_value is not None:
+                    self.grounded_values[seed_idx] = grounded_value
+            else:                                                    # trailing partial episode (:551-578)
+                if grounded:
+                    score, max_score = self._grounded_score(rec, None, values, actor, seed, False, positive)
+                else:
+                    score, max_score = float(rec["mean_score"]), float(rec["max_score"])
+                if self.sample_full_distribution and seed in self.staging_seed_set:
+                    self._partial_update_seed_score_buffer(actor, seed, score, num_steps)
+                else:
+                    self._partial_update_seed_score(actor, seed, score, max_score, num_steps)
+
+    def after_update(self):
+        """Flush partial scores (policy changed, logits stale) — reference :580-599."""
+        if not self._has_working_seed_buffer:
+            return
+        for actor_index, seed_idx in zip(*np.nonzero(self.partial_seed_scores)):      # row-major == actor-major
+            if self.partial_seed_scores[actor_index][seed_idx] != 0:
+                self.update_seed_score(int(actor_index), self.seeds[seed_idx], 0, float("-inf"), 0)
+        self.partial_seed_scores.fill(0)
+        self.partial_seed_steps.fill(0)
+        if self.sample_full_distribution:
+            for actor_index in range(self.num_actors):
+                for seed in list(self.partial_seed_scores_buffer[actor_index].keys()):
+                    if self.partial_seed_scores_buffer[actor_index].get(seed, 0) > 0:
+                        self.update_seed_score(actor_index, seed, 0, float("-inf"), 0)
+
+    # ---- sampling (reference :601-750) -----------------------------------------------------------
+    def _update_staleness(self, selected_idx):
+        if self.staleness_coef > 0:
+            self.seed_staleness = self.seed_staleness + 1
+            self.seed_staleness[selected_idx] = 0
+
+    def sample_replay_decision(self):
+        if self.sample_full_distribution:
+            filled = self._proportion_filled
+            if self.seed_buffer_size <= 0:
+                return False
+            if self.replay_schedule == "fixed":
+                return bool(filled >= self.rho and np.random.rand() < self.replay_prob)
+            return bool(filled >= self.rho and np.random.rand() < min(filled, self.replay_prob))
+        if self.replay_schedule == "fixed":
+            seen = self._proportion_filled
+            if seen >= self.rho:
+                if np.random.rand() < self.replay_prob or not seen < 1.0:
+                    return True
+            return False
+        seen = self._proportion_filled
+        return bool(seen >= self.rho and np.random.rand() < seen)
+
+    def observe_external_unseen_sample(self, seeds, solvable=None):
+        for i, seed in enumerate(seeds):
+            self.running_sample_count += 1
+            if not (seed in self.staging_seed_set or seed in self.working_seed_set):
+                self.seed2timestamp_buffer[seed] = self.running_sample_count
+                self.staging_seed_set.add(seed)
+                if solvable is not None:
+                    if not self.track_solvable:
+                        self._init_solvable_tracking()
+                    self.staging_seed2solvable[seed] = solvable[i]
+            else:
+                seed_idx = self.seed2index.get(seed, None)
+                if seed_idx is not None:
+                    self._update_staleness(seed_idx)
+
+    def sample_replay_level(self, update_staleness=True):
+        return self._sample_replay_level(update_staleness=update_staleness)
+
+    def _replay_distribution(self):
+        w = self.sample_weights()
+        if np.isclose(np.sum(w), 0):
+            w = np.ones_like(self.seeds, dtype=np.float64) / len(self.seeds)
+            w = w * (1 - self.unseen_seed_weights)
+            w /= np.sum(w)
+        elif np.sum(w, 0) != 1.0:
+            w = w / np.sum(w, 0)
+        return w
+
+    def _sample_replay_level(self, update_staleness=True):
+        w = self._replay_distribution()
+        seed_idx = np.random.choice(range(len(self.seeds)), 1, p=w)[0]
+        seed = self.seeds[seed_idx]
+        if update_staleness:
+            self._update_staleness(seed_idx)
+        return int(seed)
+
+    def sample_replay_levels(self, n, update_staleness=True):
+        """n sequential draws of sample_replay_level() (the runner's per-env loop, adversarial_runner.py:463);
+        same draws and staleness bookkeeping as n separate calls."""
+        return [self._sample_replay_level(update_staleness=update_staleness) for _ in range(n)]
+
+    def _sample_unseen_level(self):
+        if self.sample_full_distribution:
+            seed = int(np.random.randint(1, INT32_MAX))
+            while seed in self.staging_seed_set or seed in self.working_seed_set:
+                seed = int(np.random.randint(1, INT32_MAX))
+            self.seed2timestamp_buffer[seed] = self.running_sample_count
+            self.staging_seed_set.add(seed)
+        else:
+            w = self.unseen_seed_weights / self.unseen_seed_weights.sum()
+            seed_idx = np.random.choice(range(len(self.seeds)), 1, p=w)[0]
+            seed = self.seeds[seed_idx]
+            self._update_staleness(seed_idx)
+        return int(seed)
+
+    def sample(self, strategy=None):
+        if strategy == "full_distribution":
+            raise ValueError("One-off sampling via full_distribution strategy is not supported.")
+        self.running_sample_count += 1
+        strategy = strategy or self.strategy
+        if not self.sample_full_distribution:
+            if strategy == "random":
+                return int(self.seeds[np.random.choice(range(len(self.seeds)))])
+            if strategy == "sequential":
+                seed_idx = self.next_seed_index
+                self.next_seed_index = (self.next_seed_index + 1) % len(self.seeds)
+                return int(self.seeds[seed_idx])
+        return self._sample_replay_level() if self.sample_replay_decision() else self._sample_unseen_level()
+
+    def sample_weights(self):
+        weights = self._score_transform(self.score_transform, self.temperature, self.seed_scores)
+        weights = weights * (1 - self.unseen_seed_weights)
+        z = np.sum(weights)
+        if z > 0:
+            weights /= z
+        else:
+            weights = np.ones_like(weights, dtype=np.float64) / len(weights)
+            weights = weights * (1 - self.unseen_seed_weights)
+            weights /= np.sum(weights)
+        if self.staleness_coef > 0:
+            sw = self._score_transform(self.staleness_transform, self.staleness_temperature, self.seed_staleness)
+            sw = sw * (1 - self.unseen_seed_weights)
+            z = np.sum(sw)
+            if z > 0:
+                sw /= z
+            else:
+                sw = 1.0 / len(sw) * (1 - self.unseen_seed_weights)
+            weights = (1 - self.staleness_coef) * weights + self.staleness_coef * sw
+        return weights
+
+    def _score_transform(self, transform, temperature, scores):
+        if transform == "constant":
+            weights = np.ones_like(scores)
+        if transform == "max":
+            weights = np.zeros_like(scores)
+            scores = scores[:]
+            scores[self.unseen_seed_weights > 0] = -float("inf")
+            argmax = np.random.choice(np.flatnonzero(np.isclose(scores, scores.max())))
+            weights[argmax] = 1.0
+        elif transform == "eps_greedy":
+            weights = np.zeros_like(scores)
+            weights[scores.argmax()] = 1.0 - self.eps
+            weights += self.eps / len(self.seeds)
+        elif transform in ("rank", "match_rank"):
+            base = scores if transform == "rank" else np.array([(1 - s) * s for s in scores])
+            temp = np.flip(base.argsort())
+            ranks = np.empty_like(temp)
+            ranks[temp] = np.arange(len(temp)) + 1
+            weights = 1 / ranks ** (1.0 / temperature)
+        elif transform == "power":
+            eps = 0 if self.staleness_coef > 0 else 1e-3
+            weights = (np.array(scores).clip(0) + eps) ** (1.0 / temperature)
+        elif transform == "softmax":
+            weights = np.exp(np.array(scores) / temperature)
+        elif transform == "match":
+            weights = np.array([(1 - s) * s for s in scores]) ** (1.0 / temperature)
+        return weights
+
+    @property
+    def solvable_mass(self):
+        if self.track_solvable:
+            return np.sum(self.sample_weights()[self.seed_solvable])
+        return 1.0
+
+    @property
+    def max_score(self):
+        return max(self.seed_scores)
+
+    def __getstate__(self):                    # checkpoints pickle the sampler (adversarial_runner.py:214)
+        d = dict(self.__dict__)
+        d["_scorer"] = None
+        return d

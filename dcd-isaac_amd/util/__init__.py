@@ -1,0 +1,130 @@
+"""Factories and helpers with the reference's names (reference: util/__init__.py:59-252)."""
+import argparse
+import csv
+import os
+import random
+import shutil
+
+import numpy as np
+import torch
+
+from envs.registration import make as gym_make
+from envs.wrappers import HipAdversarialVecEnv
+from .make_agent import make_agent  # noqa: F401
+
+
+class DotDict(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+    __delattr__ = dict.__delitem__
+
+    def __init__(self, dct=None):
+        super().__init__()
+        for k, v in (dct or {}).items():
+            self[k] = DotDict(v) if hasattr(v, "keys") else v
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("yes", "true", "t", "y", "1"):
+        return True
+    if v.lower() in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Boolean value expected.")
+
+
+def array_to_csv(a):
+    return ",".join(str(x) for x in a)
+
+
+def cprint(condition, *args, **kwargs):
+    if condition:
+        print(*args, **kwargs)
+
+
+def seed(seed):
+    """train.py:60-61: torch / numpy / python RNGs."""
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def safe_checkpoint(state_dict, path, index=None, archive_interval=None):
+    """Atomic torch.save (reference :59-69): write *_tmp, os.replace, optional archive copy."""
+    filename, ext = os.path.splitext(path)
+    tmp = f"{filename}_tmp{ext}"
+    torch.save(state_dict, tmp)
+    os.replace(tmp, path)
+    if index is not None and archive_interval is not None and archive_interval > 0 and index % archive_interval == 0:
+        shutil.copy(path, f"{filename}_{index}{ext}")
+
+
+def save_images(images, path=None, normalize=False, channels_first=False):
+    raise NotImplementedError("level screenshots (train.py:204-232) are UI, outside the GPU hot path")
+
+
+def get_obs_at_index(obs, i):
+    if isinstance(obs, dict):
+        return {k: obs[k][i] for k in obs.keys()}
+    return obs[i]
+
+
+def set_obs_at_index(obs, obs_, i):
+    if isinstance(obs, dict):
+        for k in obs.keys():
+            obs[k][i] = obs_[k].squeeze(0)
+    else:
+        obs[i] = obs_[0].squeeze(0)
+
+
+def is_discrete_actions(env, adversary=False):
+    space = env.adversary_action_space if adversary else env.action_space
+    return space.__class__.__name__ == "Discrete"
+
+
+def is_dense_reward_env(env_name):
+    return env_name.startswith("CarRacing")
+
+
+def _make_env(args):
+    if not args.env_name.startswith("MultiGrid"):
+        raise ValueError(f"{args.env_name}: only the MultiGrid path is built (SURVEY §8)")
+    kwargs = {"seed": args.seed}
+    if args.singleton_env:
+        kwargs["fixed_environment"] = True
+    if vars(args).get("use_global_critic") or vars(args).get("use_global_policy"):
+        raise NotImplementedError("MultiGridFullyObsWrapper (global critic) is outside the hot path")
+    return gym_make(args.env_name, **kwargs)
+
+
+def create_parallel_env(args, adversary=True, device=None, env_index_base=0):
+    """(venv, ued_venv) as util/__init__.py:184-220; the whole wrapper stack is one HipAdversarialVecEnv."""
+    if vars(args).get("normalize_returns", False):
+        raise NotImplementedError("VecNormalize(ret=True) is off in every MultiGrid config; not supported")
+    if device is None:
+        device = "cuda:0"
+    make_fn = lambda: _make_env(args)
+    venv = HipAdversarialVecEnv([make_fn] * args.num_processes, adversary=adversary, device=device,
+                                env_index_base=env_index_base, engine_seed=args.seed)
+    if args.singleton_env:
+        seeds = [args.seed] * args.num_processes
+    else:
+        seeds = [env_index_base + i for i in range(args.num_processes)]
+    venv.set_seed(seeds)
+    return venv, venv
+
+
+def make_plr_args(args, obs_space, action_space):
+    return dict(seeds=[], obs_space=obs_space, action_space=action_space, num_actors=args.num_processes,
+                strategy=args.level_replay_strategy, replay_schedule=args.level_replay_schedule,
+                score_transform=args.level_replay_score_transform, temperature=args.level_replay_temperature,
+                eps=args.level_replay_eps, rho=args.level_replay_rho, replay_prob=args.level_replay_prob,
+                alpha=args.level_replay_alpha, staleness_coef=args.staleness_coef,
+                staleness_transform=args.staleness_transform, staleness_temperature=args.staleness_temperature,
+                sample_full_distribution=args.train_full_distribution,
+                seed_buffer_size=args.level_replay_seed_buffer_size,
+                seed_buffer_priority=args.level_replay_seed_buffer_priority,
+                use_dense_rewards=is_dense_reward_env(args.env_name), gamma=args.gamma)

@@ -272,11 +272,14 @@ def gen_ppo():
     rng = np.random.default_rng(7)
     img = rng.integers(0, 11, (T + 1, B, 3, 5, 5)).astype(np.float32) / np.float32(10.0)
     direction = rng.integers(0, 4, (T + 1, B, 1)).astype(np.float32)
-    masks = (rng.random((T + 1, B, 1)) > 0.15).astype(np.float32)
+    masks = (rng.random((T + 1, B, 1)) > 0.3).astype(np.float32)
     masks[0] = 1
     masks[T] = 0
     bad = np.ones_like(masks)
-    bad[(masks == 0) & (rng.random(masks.shape) < 0.6)] = 0
+    bad[(masks == 0) & (rng.random(masks.shape) < 0.8)] = 0
+    bad[:, 0] = 1
+    bad[5, 0] = 0          # env 0: exactly one truncated step (the reference skips it, storage.py:214-216)
+    masks[5, 0] = 0
     rewards = (rng.random((T, B, 1)) * (rng.random((T, B, 1)) < 0.2)).astype(np.float32)
     algo = PPO(net, clip_param=0.2, ppo_epoch=2, num_mini_batch=1, value_loss_coef=0.5, entropy_coef=0.01,
                lr=1e-4, eps=1e-5, max_grad_norm=0.5, clip_value_loss=True, log_grad_norm=True)

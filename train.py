@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""train.py — DCD training driver with the reference's flags and loop shape (reference: train.py:38-238),
+on the MI355X engine.  One process per GPU (launch with torch.distributed.run for several).
+
+  python train.py --env_name MultiGrid-GoalLastFewerBlocksAdversarial-v0 --ued_algo paired \
+      --num_processes 4096 --num_steps 256 --handle_timelimits true --recurrent_adversary_env true \
+      --num_env_steps 100000000 --log_interval 1
+
+Logging/checkpoint file formats (FileWriter, screenshots, Evaluator on the fixed mazes) are rows of
+SURVEY §8f ("next") and are not built this round: stats go to stdout as JSON lines, checkpoints use
+the reference's state_dict layout through util.safe_checkpoint.
+"""
+import json
+import os
+import sys
+import timeit
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dcd-isaac_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from arguments import parser  # noqa: E402
+from envs.runners import AdversarialRunner  # noqa: E402
+from util import create_parallel_env, make_agent, make_plr_args, safe_checkpoint, seed  # noqa: E402
+from util import distributed as D  # noqa: E402
+
+
+def main():
+    os.environ["OMP_NUM_THREADS"] = "1"
+    args = parser.parse_args()
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(args.device or f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    world = D.init(device=device)
+    rank = D.rank()
+    if world > 1 and args.use_plr:
+        raise NotImplementedError("sharded PLR (single LevelSampler on rank 0) is exercised by bench.py; "
+                                  "the training driver shards PAIRED / DR this round")
+    seed(args.seed + rank)
+    pg = torch.distributed.group.WORLD if world > 1 else None
+    venv, ued_venv = create_parallel_env(args, device=device, env_index_base=rank * args.num_processes)
+    agent = make_agent("agent", venv, args, device, process_group=pg)
+    adversary_agent = adversary_env = None
+    is_training_env = args.ued_algo in ["paired", "flexible_paired", "minimax"]
+    is_paired = args.ued_algo in ["paired", "flexible_paired"]
+    if is_paired:
+        adversary_agent = make_agent("adversary_agent", venv, args, device, process_group=pg)
+    if is_training_env or args.ued_algo == "domain_randomization":
+        adversary_env = make_agent("adversary_env", venv, args, device, process_group=pg)
+    if args.ued_algo == "domain_randomization" and args.use_plr and not args.use_reset_random_dr:
+        adversary_env.random()
+    plr_args = make_plr_args(args, venv.observation_space, venv.action_space) if args.use_plr else None
+    runner = AdversarialRunner(args=args, venv=venv, agent=agent, ued_venv=ued_venv, adversary_agent=adversary_agent,
+                               adversary_env=adversary_env, flexible_protagonist=False, train=True, plr_args=plr_args,
+                               device=device)
+    num_updates = int(args.num_env_steps) // args.num_steps // (args.num_processes * world)
+    ckpt = os.path.expandvars(os.path.expanduser(os.path.join(args.log_dir, args.xpid, "model.tar")))
+    last, t0 = 0, timeit.default_timer()
+    for j in range(num_updates):
+        stats = runner.run()
+        if rank == 0 and j % args.log_interval == 0:
+            torch.cuda.synchronize()
+            now = timeit.default_timer()
+            n = j + 1 - last
+            sps = n * args.num_processes * world * args.num_steps / (now - t0)       # train.py:184
+            last, t0 = j + 1, now
+            row = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else None)
+                   for k, v in stats.items() if not hasattr(v, "__len__")}
+            row.update(sps=sps, update=j)
+            print(json.dumps(row), flush=True)
+        if rank == 0 and args.checkpoint and j > 0 and j % args.checkpoint_interval == 0:
+            os.makedirs(os.path.dirname(ckpt), exist_ok=True)
+            safe_checkpoint({"runner_state_dict": runner.state_dict()}, ckpt, index=j, archive_interval=args.archive_interval)
+    venv.close()
+
+
+if __name__ == "__main__":
+    main()
