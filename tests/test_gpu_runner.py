@@ -1,0 +1,165 @@
+"""-m gpu: AdversarialRunner end to end on small batches (PAIRED, DR, robust PLR, ACCEL, minimax), and
+the fused device-level rollout against the reference's host-side step loop restated on top of the
+reference-compatible `step_env` API (adversarial_runner.py:497-588)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_args(**kw):
+    from arguments import parser
+    args = parser.parse_args([])
+    base = dict(env_name="MultiGrid-GoalLastFewerBlocksAdversarial-v0", num_processes=64, num_steps=48, ppo_epoch=1,
+                adv_ppo_epoch=1, handle_timelimits=True, recurrent_adversary_env=True, log_grad_norm=True, seed=3)
+    base.update(kw)
+    for k, v in base.items():
+        assert hasattr(args, k), k
+        setattr(args, k, v)
+    return args
+
+
+def build(args):
+    from envs.runners import AdversarialRunner
+    from util import create_parallel_env, make_agent, make_plr_args, seed
+    seed(args.seed)
+    venv, ued_venv = create_parallel_env(args, device=DEV)
+    agent = make_agent("agent", venv, args, DEV)
+    adversary_agent = make_agent("adversary_agent", venv, args, DEV) if args.ued_algo in ("paired", "flexible_paired") else None
+    adversary_env = make_agent("adversary_env", venv, args, DEV)
+    plr_args = make_plr_args(args, venv.observation_space, venv.action_space) if args.use_plr else None
+    runner = AdversarialRunner(args=args, venv=venv, agent=agent, ued_venv=ued_venv, adversary_agent=adversary_agent,
+                               adversary_env=adversary_env, train=True, plr_args=plr_args, device=DEV)
+    return runner, venv
+
+
+REF_KEYS = ["steps", "total_episodes", "total_seeds", "total_student_grad_updates", "mean_agent_return", "agent_value_loss",
+            "agent_pg_loss", "agent_dist_entropy", "mean_adversary_agent_return", "adversary_value_loss",
+            "adversary_pg_loss", "adversary_dist_entropy"]
+
+
+@pytest.mark.parametrize("algo", ["paired", "flexible_paired", "minimax"])
+def test_paired_family_runs(algo):
+    args = make_args(ued_algo=algo)
+    runner, venv = build(args)
+    before = {k: v.clone() for k, v in runner.agents["adversary_env"].algo.actor_critic.state_dict().items()}
+    for j in range(2):
+        stats = runner.run()
+    for k in REF_KEYS + ["mean_env_return", "adversary_env_pg_loss", "num_blocks", "passable_ratio", "shortest_path_length"]:
+        assert k in stats, k
+    assert stats["steps"] == 2 * 64 * 48 and stats["total_seeds"] == 2 * 64
+    assert np.isfinite(stats["agent_value_loss"]) and np.isfinite(stats["adversary_env_value_loss"])
+    assert 0 <= stats["mean_env_return"] <= 1 or algo == "minimax"
+    after = runner.agents["adversary_env"].algo.actor_critic.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before)          # teacher learned from the regret
+    sd = runner.state_dict()
+    assert set(sd) >= {"agent_state_dict", "optimizer_state_dict", "num_updates", "level_store", "level_samplers"}
+    assert sd["num_updates"] == 2
+    venv.close()
+
+
+def test_domain_randomization_runs():
+    args = make_args(ued_algo="domain_randomization", recurrent_adversary_env=False)
+    runner, venv = build(args)
+    s = [runner.run() for _ in range(2)][-1]
+    assert s["total_seeds"] >= 2 * 64 and s["total_episodes"] > 0 and np.isfinite(s["agent_value_loss"])
+    venv.close()
+
+
+def test_robust_plr_runs_and_fills_buffer():
+    args = make_args(ued_algo="domain_randomization", use_plr=True, use_reset_random_dr=True, no_exploratory_grad_updates=True,
+                     level_replay_strategy="grounded_signed_value_loss", level_replay_score_transform="rank",
+                     level_replay_prob=0.5, level_replay_rho=0.5, level_replay_seed_buffer_size=100, staleness_coef=0.3,
+                     log_plr_buffer_stats=True, recurrent_adversary_env=False, num_steps=64,
+                     env_name="MultiGrid-MiniGoalLastAdversarial-v0")        # 6x6, 50-step episodes: levels complete
+    runner, venv = build(args)
+    np.random.seed(0)
+    replays = 0
+    for j in range(8):
+        s = runner.run()
+        replays += int(runner.sampled_level_info["level_replay"])
+    sampler = runner.level_samplers["agent"]
+    assert sampler.working_seed_buffer_size > 50 and replays >= 1
+    assert len(runner.level_store) >= sampler.working_seed_buffer_size
+    assert s["total_student_grad_updates"] == replays          # robust PLR: gradients only on replay levels
+    assert "agent_plr_max_score" in s and np.isfinite(s["agent_plr_max_score"])
+    w = sampler.sample_weights()
+    assert abs(w.sum() - 1) < 1e-9 and (w >= 0).all()
+    venv.close()
+
+
+def test_accel_edits_levels():
+    args = make_args(ued_algo="domain_randomization", use_plr=True, use_reset_random_dr=True, no_exploratory_grad_updates=True,
+                     use_editor=True, level_editor_prob=1.0, num_edits=5, base_levels="easy",
+                     level_replay_strategy="positive_value_loss", level_replay_prob=0.8, level_replay_rho=0.3,
+                     level_replay_seed_buffer_size=64, recurrent_adversary_env=False, num_steps=64,
+                     env_name="MultiGrid-MiniGoalLastAdversarial-v0")
+    runner, venv = build(args)
+    np.random.seed(1)
+    for j in range(8):
+        s = runner.run()
+    assert runner.total_num_edits >= 1
+    assert max(len(v) for v in runner.level_store.seed2parent.values()) >= 1      # edited levels carry lineage
+    venv.close()
+
+
+def test_device_rollout_equals_reference_host_loop():
+    """Same levels, same action tape: storage filled by the fused device path == storage filled by the
+    reference's step loop (restated here) over the compat API."""
+    from algos import RolloutStorage
+    from envs.wrappers import HipAdversarialVecEnv
+    from envs.registration import make
+    import dcd_hip
+    B, T = 96, 300
+    mk = lambda: make("MultiGrid-GoalLastFewerBlocksAdversarial-v0", seed=0)
+    va = HipAdversarialVecEnv([mk] * B, device=DEV, engine_seed=5)
+    vb = HipAdversarialVecEnv([mk] * B, device=DEV, engine_seed=5)
+    for v in (va, vb):
+        v.set_seed(list(range(B)))
+        v.reset()
+        for k in range(27):
+            loc = dcd_hip.engine.random_actions(B, 0, 2, k, 169, DEV)
+            v.step_adversary_device(loc, {})
+    sa = RolloutStorage(None, T, B, va.observation_space, va.action_space, 4, "lstm", use_proper_time_limits=True, device=DEV)
+    sb = RolloutStorage(None, T, B, vb.observation_space, vb.action_space, 4, "lstm", use_proper_time_limits=True, device=DEV)
+    acts = dcd_hip.engine.random_actions(B, 0, 3, 0, 7, DEV, T=T)
+    # --- device path
+    va.reset_agent_device(sa.student_obs_out(0))
+    for t in range(T):
+        va.step_env_device(acts[t], sa.step_out(t), last_step=(t == T - 1))
+        sa.advance()
+    # --- reference host loop (adversarial_runner.py:484-588) over the compat API
+    obs = vb.reset_agent()
+    sb.copy_obs_to_index(obs, 0)
+    eps = 0
+    for t in range(T):
+        obs, reward, done, infos = vb.step_env(acts[t].cpu().view(-1, 1), reset_random=False)
+        if t >= T - 1:
+            for i, d in enumerate(done):
+                if not d:
+                    infos[i]["cliffhanger"] = True
+                    infos[i]["truncated"] = True
+                    infos[i]["truncated_obs"] = {k: obs[k][i] for k in obs}
+            done = np.ones_like(done, dtype=float)
+        for i, info in enumerate(infos):
+            if "episode" in info:
+                eps += 1
+                if "truncated_obs" in info:
+                    sb.insert_truncated_obs(info["truncated_obs"], index=i)
+        masks = torch.FloatTensor([[0.0] if d else [1.0] for d in done])
+        bad = torch.FloatTensor([[0.0] if "truncated" in info else [1.0] for info in infos])
+        cliff = torch.FloatTensor([[0.0] if "cliffhanger" in info else [1.0] for info in infos])
+        z = torch.zeros(B, 1)
+        sb.insert(obs, (z.repeat(1, 4), z.repeat(1, 4)), z.long(), z, torch.zeros(B, 7), z, reward, masks, bad,
+                  cliffhanger_masks=cliff)
+    assert eps > 20
+    for name in ("rewards", "masks", "bad_masks", "cliffhanger_masks"):
+        assert torch.equal(getattr(sa, name), getattr(sb, name)), name
+    for k in ("image", "direction"):
+        assert torch.equal(sa.obs[k], sb.obs[k]), k
+        assert torch.equal(sa.truncated_obs[k], sb.truncated_obs[k]), "truncated_" + k
+    assert int((sa.ep_info & 1).sum()) == eps
+    assert torch.equal(va.get_encodings_device(), vb.get_encodings_device())
+    va.close(); vb.close()
