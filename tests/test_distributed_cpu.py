@@ -1,0 +1,132 @@
+"""CPU, world_size 2 over gloo: the exchange steps of the sharded path.
+
+  * PPO with gradient all-reduce + global advantage moments on 2 ranks x B/2 envs == one process
+    with B envs (same parameters after the update, fp32 tolerance);
+  * episode-score records all-gathered to every rank in global actor order; rank 0's LevelSampler
+    fed with them == a single-process sampler on the concatenated batch.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+G = os.path.join(HERE, "golden")
+T, B = 12, 4
+
+
+def _setup(rank, world, port):
+    for p in (ROOT, os.path.join(ROOT, "dcd-isaac_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _build(g, envs, process_group):
+    from algos import ACAgent, PPO, RolloutStorage
+    from envs import spaces
+    from models import MultigridNetwork
+    obs = {"image": spaces.Box(0, 255, (3, 5, 5), "uint8"), "direction": spaces.Box(0, 3, (1,), "uint8")}
+    net = MultigridNetwork(obs, spaces.Discrete(7), scalar_fc=5, scalar_dim=4, recurrent_arch="lstm", recurrent_hidden_size=256)
+    net.load_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w_") and not k.startswith("w_after_")})
+    n = len(envs)
+    st = RolloutStorage(net, T, n, obs, spaces.Discrete(7), 256, recurrent_arch="lstm", use_proper_time_limits=False)
+    sel = lambda a: torch.from_numpy(np.ascontiguousarray(a[:, envs]))
+    st.obs["image"].copy_(sel(g["img"])); st.obs["direction"].copy_(sel(g["direction"]))
+    st.masks.copy_(sel(g["masks"])); st.rewards.copy_(sel(g["rewards"]))
+    st.recurrent_hidden_states.copy_(sel(g["hidden"])); st.actions.copy_(sel(g["act_actions"]))
+    st.value_preds[:-1].copy_(sel(g["act_values"])); st.value_preds[-1].copy_(torch.from_numpy(g["next_value"][envs]))
+    st.action_log_probs.copy_(sel(g["action_log_probs"])); st.returns.copy_(sel(g["returns"]))
+    algo = PPO(net, clip_param=0.2, ppo_epoch=2, num_mini_batch=1, value_loss_coef=0.5, entropy_coef=0.01, lr=1e-4,
+               eps=1e-5, max_grad_norm=0.5, clip_value_loss=True, process_group=process_group)
+    return ACAgent(algo, st), net
+
+
+def _ppo_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    g = np.load(os.path.join(G, "ppo.npz"))
+    envs = [0, 1] if rank == 0 else [2, 3]
+    agent, net = _build(g, envs, dist.group.WORLD)
+    torch.manual_seed(2)
+    vl, al, ent, _ = agent.update()
+    if rank == 0:
+        torch.save({"sd": net.state_dict(), "losses": (vl, al, ent)}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ppo_equals_single_process():
+    for p in (ROOT, os.path.join(ROOT, "dcd-isaac_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(G, "ppo.npz"))
+    agent, net = _build(g, [0, 1, 2, 3], None)
+    torch.manual_seed(2)
+    ref_losses = agent.update()[:3]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "r0.pt")
+        mp.spawn(_ppo_worker, args=(2, 29533, out), nprocs=2, join=True)
+        got = torch.load(out, weights_only=False)
+    np.testing.assert_allclose(got["losses"], ref_losses, rtol=1e-4, atol=1e-7)
+    for k, v in net.state_dict().items():
+        np.testing.assert_allclose(got["sd"][k].numpy(), v.numpy(), rtol=0, atol=3e-6, err_msg=k)
+
+
+def _records_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    from oracle import orc
+    from util import distributed as D
+    g = np.load(os.path.join(G, "scans.npz"))
+    d = {k[len("small_"):]: g[k][..., 0] if g[k].ndim == 3 and g[k].shape[-1] == 1 else g[k] for k in g.files if k.startswith("small_")}
+    half = slice(0, 4) if rank == 0 else slice(4, 8)
+    recs = orc.episode_scores(d["gae"][:, half], d["value_preds"][:, half], d["rewards"][:, half], d["masks"][:, half],
+                              d["cliffhanger_masks"][:, half], d["level_seeds"][:, half], None, 1, 0.995)
+    parts = D.all_gather_records(recs, "cpu")
+    regret = D.all_gather_tensor(torch.full((4, 1), float(rank)))
+    assert regret.shape == (8, 1) and regret[:4].eq(0).all() and regret[4:].eq(1).all()
+    if rank == 0:
+        np.save(out_path, np.array([len(p) for p in parts]))
+        np.save(out_path + ".recs.npy", np.concatenate([np.ascontiguousarray(p).view(np.int32).reshape(-1, 8) for p in parts]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class _Space:
+    n = 7
+
+
+def test_gathered_records_feed_one_sampler():
+    from level_replay import LevelSampler
+    from oracle import orc
+    g = np.load(os.path.join(G, "scans.npz"))
+    sq = lambda a: a[..., 0]
+    d = {k[len("small_"):]: g[k] for k in g.files if k.startswith("small_")}
+    whole = orc.episode_scores(sq(d["gae"]), sq(d["value_preds"]), sq(d["rewards"]), sq(d["masks"]),
+                               sq(d["cliffhanger_masks"]), sq(d["level_seeds"]), None, 1, 0.995)
+    with tempfile.TemporaryDirectory() as dd:
+        out = os.path.join(dd, "counts.npy")
+        mp.spawn(_records_worker, args=(2, 29534, out), nprocs=2, join=True)
+        counts = np.load(out)
+        flat = np.load(out + ".recs.npy")
+    parts, off = [], 0
+    for c in counts:
+        parts.append(flat[off:off + c].copy().view(orc.EPISODE_REC).reshape(c))
+        off += c
+    assert sum(counts) == len(whole)
+    mk = lambda: LevelSampler(list(range(1, 12)), None, _Space(), num_actors=8, strategy="positive_value_loss",
+                              score_transform="rank", temperature=0.1, staleness_coef=0.3, alpha=1.0)
+    a, b = mk(), mk()
+    a.update_with_records(whole)
+    for r, part in enumerate(parts):
+        b.update_with_records(part, actor_offset=4 * r)            # global actor = rank * B + local actor
+    assert np.array_equal(a.seed_scores, b.seed_scores) and np.array_equal(a.partial_seed_scores, b.partial_seed_scores)
+    assert np.array_equal(a.partial_seed_steps, b.partial_seed_steps)
