@@ -27,6 +27,7 @@ using namespace dcd;
 namespace {
 
 constexpr int WAVE = 64;
+constexpr int NT = 256;            // threads per workgroup: wave 0 runs the per-env logic, all 4 waves stage and emit
 constexpr int LP = 272;            // LDS pitch of one env record
 constexpr int MAX_OP = 152;        // staged u8 obs per env: V*V*3 + dir, padded (V<=7 -> 148)
 
@@ -34,18 +35,6 @@ __device__ __forceinline__ int obs_pitch(int V) { return (V * V * 3 + 1 + 3) & ~
 
 typedef DCD_REC uint8_t lds_u8;      // address_space(3) in the device pass, plain in the host pass
 __device__ __forceinline__ lds_u8* as_lds(uint8_t* p) { return (lds_u8*)p; }
-
-// ---- wave-cooperative record staging ------------------------------------------------------
-// rows: env index of each of the workgroup's `n` rows comes from env_of[row] (LDS int array).
-// ROWS*16 16-byte chunks over 64 lanes: loads are issued first (all in flight), LDS writes after.
-__device__ __forceinline__ void stage_out(const uint8_t* lds, uint8_t* __restrict__ rec, const int* env_of,
-                                          int n, int lane) {
-  for (int q = lane; q < n * 16; q += WAVE) {
-    const int row = q >> 4, c = q & 15;
-    const uint4 v = *reinterpret_cast<const uint4*>(lds + row * LP + c * 16);
-    *reinterpret_cast<uint4*>(rec + (size_t)env_of[row] * REC_BYTES + c * 16) = v;
-  }
-}
 
 // k/10.0 evaluated in fp64 and rounded once to fp32 (VecPreprocessImageWrapper._preprocess,
 // obs_wrappers.py:90-91,96) for every byte value enc3 can produce (type<=10, colour<=5, state<=3).
@@ -55,36 +44,76 @@ __constant__ float kDiv10[16] = {(float)(0 / 10.0), (float)(1 / 10.0), (float)(2
                                  (float)(12 / 10.0), (float)(13 / 10.0), (float)(14 / 10.0), (float)(15 / 10.0)};
 // LUTs shared by the emission code, indexed by packed cell code: the 3 encoding bytes and their /10 floats
 struct Luts { uint32_t enc[64]; float f[3][64]; float div10[16]; };
-__device__ __forceinline__ void init_luts(Luts& l, int lane) {
-  const uint32_t t = lane < C_END ? enc3((uint8_t)lane) : 0u;
-  l.enc[lane] = t;
-  l.f[0][lane] = kDiv10[t & 15]; l.f[1][lane] = kDiv10[(t >> 8) & 15]; l.f[2][lane] = kDiv10[(t >> 16) & 15];
-  if (lane < 16) l.div10[lane] = kDiv10[lane];
+__device__ __forceinline__ void init_luts(Luts& l, int tid) {
+  if (tid < 64) {
+    const uint32_t t = tid < C_END ? enc3((uint8_t)tid) : 0u;
+    l.enc[tid] = t;
+    l.f[0][tid] = kDiv10[t & 15]; l.f[1][tid] = kDiv10[(t >> 8) & 15]; l.f[2][tid] = kDiv10[(t >> 16) & 15];
+    if (tid < 16) l.div10[tid] = kDiv10[tid];
+  }
+}
+
+// ---- workgroup-cooperative record staging: n rows x 16 chunks of 16 B over NT threads ---------
+template <int ROWS>
+struct StageBuf { uint4 v[(ROWS * 16 + NT - 1) / NT]; };
+template <int ROWS, class RowToEnv>
+__device__ __forceinline__ void stage_load(StageBuf<ROWS>& sb, const uint8_t* __restrict__ rec, RowToEnv env_of, int n, int tid) {
+#pragma unroll
+  for (int i = 0; i < (ROWS * 16 + NT - 1) / NT; ++i) {
+    const int q = i * NT + tid, row = q >> 4, c = q & 15;
+    sb.v[i] = make_uint4(0, 0, 0, 0);
+    if (row < n) sb.v[i] = *reinterpret_cast<const uint4*>(rec + (size_t)env_of(row) * REC_BYTES + c * 16);
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void stage_commit(const StageBuf<ROWS>& sb, uint8_t* lds, int n, int tid) {
+#pragma unroll
+  for (int i = 0; i < (ROWS * 16 + NT - 1) / NT; ++i) {
+    const int q = i * NT + tid, row = q >> 4, c = q & 15;
+    if (row < n) *reinterpret_cast<uint4*>(lds + row * LP + c * 16) = sb.v[i];
+  }
+}
+template <class RowToEnv>
+__device__ __forceinline__ void stage_out(const uint8_t* lds, uint8_t* __restrict__ rec, RowToEnv env_of, int n, int tid) {
+  for (int q = tid; q < n * 16; q += NT) {
+    const int row = q >> 4, c = q & 15;
+    *reinterpret_cast<uint4*>(rec + (size_t)env_of(row) * REC_BYTES + c * 16) = *reinterpret_cast<const uint4*>(lds + row * LP + c * 16);
+  }
 }
 
 // ---- fused render + emit of the student observation, cooperative over the workgroup -----------
-// One (env row, view cell) pair per lane-iteration: world cell through the closed-form map of
+// One (env row, view cell) pair per thread-iteration: world cell through the closed-form map of
 // multigrid.py:1080-1093, packed code from the LDS record, channel values from the code LUTs, stored
-// as fp32 CHW (/10) and/or u8 [vx][vy][c].  Consecutive lanes hit consecutive view cells of the same
+// as fp32 CHW (/10) and/or u8 [vx][vy][c].  Consecutive threads hit consecutive view cells of the same
 // env, so each channel's store is a run of contiguous floats.  Semantics == dcd::render_view.
-template <int V>
+template <int V, int ROWS>
 __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
-                                            int n, int S, int lane) {
-  constexpr int VV = V * V, H = V / 2;
+                                            int n, int S, int tid) {
+  constexpr int VV = V * V, H = V / 2, ITERS = (ROWS * VV + NT - 1) / NT;
   if (o.image_u8 || o.image_f32) {
-#pragma unroll 4
-    for (int q = lane; q < n * VV; q += WAVE) {
-      const int row = q / VV, ci = q - row * VV, vx = ci / V, vy = ci - vx * V;
-      const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + row * LP + DYN);
-      const int ax = dyn & 255, ay = (dyn >> 8) & 255, d = (dyn >> 16) & 255, carry = dyn >> 24;
-      const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
-      const int wx = ax + fx * (V - 1 - vy) - fy * (vx - H), wy = ay + fy * (V - 1 - vy) + fx * (vx - H);
-      const bool own = (vx == H && vy == V - 1), oob = (wx < 0 || wx >= S || wy < 0 || wy >= S);
-      int c = lds[row * LP + ((own || oob) ? DYN + 3 : wy * ROW + wx)];      // own cell -> carrying byte
-      if (oob && !own) c = C_WALL_GREY;
-      else if (!own && c >= C_AGENT0 && c < C_DOOR0) c = C_AGENT0 + (((c - C_AGENT0) - (d + 1)) & 3);
-      (void)carry;
-      const bool none = (ax == NOPOS);                                   // no agent placed yet: zero obs
+    int code[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {                         // phase 1: all LDS gathers in flight together
+      const int q = i * NT + tid, row = q / VV, ci = q - row * VV, vx = ci / V, vy = ci - vx * V;
+      code[i] = -1;
+      if (q < n * VV) {
+        const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + row * LP + DYN);
+        const int ax = dyn & 255, ay = (dyn >> 8) & 255, d = (dyn >> 16) & 255;
+        const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
+        const int wx = ax + fx * (V - 1 - vy) - fy * (vx - H), wy = ay + fy * (V - 1 - vy) + fx * (vx - H);
+        const bool own = (vx == H && vy == V - 1), oob = (wx < 0 || wx >= S || wy < 0 || wy >= S);
+        int c = lds[row * LP + ((own || oob) ? DYN + 3 : wy * ROW + wx)];        // own cell -> carrying byte
+        if (oob && !own) c = C_WALL_GREY;
+        else if (!own && c >= C_AGENT0 && c < C_DOOR0) c = C_AGENT0 + (((c - C_AGENT0) - (d + 1)) & 3);
+        code[i] = (ax == NOPOS) ? 64 : c;                      // 64: no agent placed yet -> zero observation
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {                         // phase 2: LUT + stores
+      const int q = i * NT + tid, row = q / VV, ci = q - row * VV;
+      if (code[i] < 0) continue;
+      const bool none = code[i] == 64;
+      const int c = none ? 0 : code[i];
       const size_t r = out_row0 + row;
       if (o.image_f32) {
         float* f = o.image_f32 + r * (3 * VV) + ci;
@@ -98,37 +127,38 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
       }
     }
   }
-  if (lane < n) {
-    const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + lane * LP + DYN);
+  if (tid < n) {
+    const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + tid * LP + DYN);
     const int d = ((dyn & 255) == NOPOS) ? 0 : ((dyn >> 16) & 255);
-    if (o.dir_u8) o.dir_u8[out_row0 + lane] = (uint8_t)d;
-    if (o.dir_f32) o.dir_f32[out_row0 + lane] = (float)d;
+    if (o.dir_u8) o.dir_u8[out_row0 + tid] = (uint8_t)d;
+    if (o.dir_f32) o.dir_f32[out_row0 + tid] = (float)d;
   }
 }
+template <int ROWS>
 __device__ __forceinline__ void render_emit_v(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
-                                              int n, int S, int V, int lane) {
-  if (V == 5) render_emit<5>(lds, lut, o, out_row0, n, S, lane);
-  else if (V == 7) render_emit<7>(lds, lut, o, out_row0, n, S, lane);
-  else render_emit<3>(lds, lut, o, out_row0, n, S, lane);
+                                              int n, int S, int V, int tid) {
+  if (V == 5) render_emit<5, ROWS>(lds, lut, o, out_row0, n, S, tid);
+  else if (V == 7) render_emit<7, ROWS>(lds, lut, o, out_row0, n, S, tid);
+  else render_emit<3, ROWS>(lds, lut, o, out_row0, n, S, tid);
 }
 
 // ---- emission of per-lane staged observations (terminal obs: rare) ---------------------------
 // sobs: [n][OP] bytes ([vx][vy][c] then dir); rows with valid[row]==0 are left untouched.
 __device__ __forceinline__ void emit_staged(const uint8_t* sobs, const Luts& lut, const DcdStudentObs& o,
-                                            size_t out_row0, int n, int V, int lane, const uint8_t* valid) {
+                                            size_t out_row0, int n, int V, int tid, const uint8_t* valid) {
   const int VV = V * V, E = VV * 3, OP = obs_pitch(V);
-  if (o.image_u8) for (int f = lane; f < n * E; f += WAVE) {
+  if (o.image_u8) for (int f = tid; f < n * E; f += NT) {
     const int row = f / E, el = f - row * E;
     if (valid[row]) o.image_u8[out_row0 * E + f] = sobs[row * OP + el];
   }
-  if (o.image_f32) for (int f = lane; f < n * E; f += WAVE) {
+  if (o.image_f32) for (int f = tid; f < n * E; f += NT) {
     const int row = f / E, el = f - row * E, c = el / VV, rem = el - c * VV;
     if (valid[row]) o.image_f32[out_row0 * E + f] = lut.div10[sobs[row * OP + rem * 3 + c] & 15];
   }
-  if (lane < n && valid[lane]) {
-    const uint8_t d = sobs[lane * OP + E];
-    if (o.dir_u8) o.dir_u8[out_row0 + lane] = d;
-    if (o.dir_f32) o.dir_f32[out_row0 + lane] = (float)d;
+  if (tid < n && valid[tid]) {
+    const uint8_t d = sobs[tid * OP + E];
+    if (o.dir_u8) o.dir_u8[out_row0 + tid] = d;
+    if (o.dir_f32) o.dir_f32[out_row0 + tid] = (float)d;
   }
 }
 
@@ -147,50 +177,40 @@ struct StepArgs {
 };
 
 #ifdef DCD_STAMPS
-#define STAMP(i) do { if (lane == 0 && a.stamps) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(i) do { if (tid == 0 && a.stamps) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
 #endif
 
-// EPB = envs per workgroup (one 64-lane wave each).  Lanes [0,EPB) run the per-env logic; ALL lanes
-// share staging and the fused render/emit.  Small batches use EPB=16 so that B=4096 still spreads
-// over all 256 CUs; large batches use EPB=64 (every lane busy in the logic phase).
+// EPB = envs per workgroup.  Threads [0,EPB) of wave 0 run the per-env logic; ALL 256 threads share
+// staging and the fused render/emit.  Small batches use EPB=16 so that B=4096 still spreads over all
+// 256 CUs; large batches use EPB=64 (every lane of the logic wave busy).
 template <bool RANDOM, int EPB>
-__global__ void __launch_bounds__(WAVE) mg_step_kernel(Params p, StepArgs a) {
+__global__ void __launch_bounds__(NT) mg_step_kernel(Params p, StepArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[EPB * LP];
   __shared__ __attribute__((aligned(16))) uint8_t sterm[EPB * MAX_OP];
-  __shared__ uint8_t term_valid[WAVE];
-  __shared__ int env_of[WAVE];
+  __shared__ uint8_t term_valid[EPB];
+  __shared__ int any_term;
   __shared__ Luts lut;
-  const int lane = threadIdx.x, env0 = blockIdx.x * EPB;
-  const int n = min(EPB, p.B - env0), env = env0 + lane;
+  const int tid = threadIdx.x, env0 = blockIdx.x * EPB;
+  const int n = min(EPB, p.B - env0), env = env0 + tid;
   const int OP = obs_pitch(p.V);
   STAMP(0);
-  env_of[lane] = env;
-  term_valid[lane] = 0;
   // issue every independent global load up front: records, action, seed (one HBM round trip in all)
-  uint4 buf[EPB / 4];
-#pragma unroll
-  for (int i = 0; i < EPB / 4; ++i) {
-    const int q = i * WAVE + lane, row = q >> 4, c = q & 15;
-    buf[i] = make_uint4(0, 0, 0, 0);
-    if (row < n) buf[i] = *reinterpret_cast<const uint4*>(a.rec + (size_t)(env0 + row) * REC_BYTES + c * 16);
-  }
+  StageBuf<EPB> sb;
+  stage_load<EPB>(sb, a.rec, [env0](int row) { return env0 + row; }, n, tid);
   int64_t act0 = 0; uint32_t seed = 0;
-  if (lane < n) { seed = a.seed[env]; if (!RANDOM) act0 = a.actions[env]; }
-  init_luts(lut, lane);
+  if (tid < n) { seed = a.seed[env]; if (!RANDOM) act0 = a.actions[env]; term_valid[tid] = 0; }
+  if (tid == 0) any_term = 0;
+  init_luts(lut, tid);
   STAMP(1);
-#pragma unroll
-  for (int i = 0; i < EPB / 4; ++i) {
-    const int q = i * WAVE + lane, row = q >> 4, c = q & 15;
-    if (row < n) *reinterpret_cast<uint4*>(lds + row * LP + c * 16) = buf[i];
-  }
+  stage_commit<EPB>(sb, lds, n, tid);
   __syncthreads();
   STAMP(2);
 
   unsigned long long episodes = 0;
-  if (lane < n) {
-    Env e = make_env(as_lds(lds + lane * LP), seed);
+  if (tid < n) {
+    Env e = make_env(as_lds(lds + tid * LP), seed);
     Metrics m = {0, 0, 0, 0}; bool mdirty = false;
     if (a.flags & DCD_STEP_RESET_RANDOM) m = a.met[env];
     StepResult r;
@@ -203,10 +223,10 @@ __global__ void __launch_bounds__(WAVE) mg_step_kernel(Params p, StepArgs a) {
         act = (int64_t)mulhi32(o[0], 7u);
       }
       const int fl = (RANDOM && k != K - 1) ? (a.flags & ~DCD_STEP_LAST) : a.flags;
-      r = env_step(e, p, m, mdirty, act, fl, as_lds(sterm + lane * OP));
+      r = env_step(e, p, m, mdirty, act, fl, as_lds(sterm + tid * OP));
       if (RANDOM) episodes += (r.info & DCD_INFO_EPISODE) ? 1 : 0;
     }
-    term_valid[lane] = r.have_term ? 1 : 0;
+    if (r.have_term) { term_valid[tid] = 1; any_term = 1; }
     STAMP(3);
     e.store_dyn();                                   // LDS copy feeds the cooperative render below
     // write-back: dyn always; cells by dirty list or whole record (LDS reads first, then the stores)
@@ -215,11 +235,11 @@ __global__ void __launch_bounds__(WAVE) mg_step_kernel(Params p, StepArgs a) {
     if (e.full_dirty) {
       uint4 rows[15];
 #pragma unroll
-      for (int y = 0; y < 15; ++y) rows[y] = *reinterpret_cast<const uint4*>(lds + lane * LP + y * ROW);
+      for (int y = 0; y < 15; ++y) rows[y] = *reinterpret_cast<const uint4*>(lds + tid * LP + y * ROW);
 #pragma unroll
       for (int y = 0; y < 15; ++y) *reinterpret_cast<uint4*>(g + y * ROW) = rows[y];
     } else {
-      const uint8_t c0 = lds[lane * LP + e.doff0], c1 = lds[lane * LP + e.doff1];
+      const uint8_t c0 = lds[tid * LP + e.doff0], c1 = lds[tid * LP + e.doff1];
       if (e.nd > 0) g[e.doff0] = c0;
       if (e.nd > 1) g[e.doff1] = c1;
     }
@@ -238,13 +258,13 @@ __global__ void __launch_bounds__(WAVE) mg_step_kernel(Params p, StepArgs a) {
   }
   __syncthreads();
   STAMP(4);
-  render_emit_v(lds, lut, a.out.obs, (size_t)env0, n, p.S, p.V, lane);     // post-auto-reset observation
+  render_emit_v<EPB>(lds, lut, a.out.obs, (size_t)env0, n, p.S, p.V, tid);     // post-auto-reset observation
   STAMP(5);
-  if (__ballot(term_valid[lane] != 0)) emit_staged(sterm, lut, a.out.term_obs, (size_t)env0, n, p.V, lane, term_valid);
+  if (any_term) emit_staged(sterm, lut, a.out.term_obs, (size_t)env0, n, p.V, tid, term_valid);
   STAMP(6);
-  if (RANDOM && a.n_episodes) {
+  if (RANDOM && a.n_episodes && tid < WAVE) {
     for (int off = 32; off > 0; off >>= 1) episodes += __shfl_down(episodes, off);
-    if (lane == 0 && episodes) atomicAdd(a.n_episodes, episodes);
+    if (tid == 0 && episodes) atomicAdd(a.n_episodes, episodes);
   }
 }
 
@@ -264,48 +284,59 @@ struct LevelArgs {
   uint8_t* enc_out;                               // OP_READ_ENC [B,S,S,3]
 };
 
-template <int OP>
-__global__ void __launch_bounds__(WAVE) mg_level_kernel(Params p, LevelArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVE * LP];
-  __shared__ int env_of[WAVE];
+// full-grid observation of the workgroup's n envs: u8 [x][y][c] and/or fp32 CHW /10, contiguous per
+// workgroup (identity rows only).  SS = compile-time grid size (0: runtime p.S).
+template <int SS>
+__device__ __forceinline__ void emit_grid(const uint8_t* lds, const Luts& lut, uint8_t* u8, float* f32, size_t row0, int n,
+                                          int S_rt, int tid) {
+  const int S = SS ? SS : S_rt, G = S * S * 3, SQ = S * S;
+  if (f32) {
+#pragma unroll 4
+    for (int f = tid; f < n * G; f += NT) {
+      const int r = f / G, el = f - r * G, c = el / SQ, cell = el - c * SQ, x = cell / S, y = cell - x * S;
+      f32[row0 * G + f] = lut.f[c][lds[r * LP + y * ROW + x]];
+    }
+  }
+  if (u8) {
+#pragma unroll 4
+    for (int f = tid; f < n * G; f += NT) {
+      const int r = f / G, el = f - r * G, cell = el / 3, c = el - cell * 3, x = cell / S, y = cell - x * S;
+      u8[row0 * G + f] = (uint8_t)(lut.enc[lds[r * LP + y * ROW + x]] >> (8 * c));
+    }
+  }
+}
+
+template <int OP, int EPB>
+__global__ void __launch_bounds__(NT) mg_level_kernel(Params p, LevelArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[EPB * LP];
+  __shared__ int env_of[EPB];
+  __shared__ uint32_t zctr[EPB];                  // per-row rng counter at which this call's random_z starts
   __shared__ Luts lut;
-  const int lane = threadIdx.x, row0 = blockIdx.x * WAVE;
-  const int n = min(WAVE, a.n_rows - row0), row = row0 + lane;
+  const int tid = threadIdx.x, row0 = blockIdx.x * EPB;
+  const int n = min(EPB, a.n_rows - row0), row = row0 + tid;
   const int S = p.S;
-  int env = -1;
-  if (lane < n) env = a.idx ? a.idx[row] : row;
-  env_of[lane] = env;
-  init_luts(lut, lane);
+  if (tid < EPB) env_of[tid] = (tid < n) ? (a.idx ? a.idx[row] : row) : -1;
+  init_luts(lut, tid);
   __syncthreads();
   {
-    uint4 buf[WAVE / 4];
-#pragma unroll
-    for (int i = 0; i < WAVE / 4; ++i) {
-      const int q = i * WAVE + lane, r = q >> 4, c = q & 15;
-      buf[i] = make_uint4(0, 0, 0, 0);
-      if (r < n) buf[i] = *reinterpret_cast<const uint4*>(a.rec + (size_t)env_of[r] * REC_BYTES + c * 16);
-    }
-#pragma unroll
-    for (int i = 0; i < WAVE / 4; ++i) {
-      const int q = i * WAVE + lane, r = q >> 4, c = q & 15;
-      if (r < n) *reinterpret_cast<uint4*>(lds + r * LP + c * 16) = buf[i];
-    }
+    StageBuf<EPB> sb;
+    stage_load<EPB>(sb, a.rec, [&](int r) { return env_of[r]; }, n, tid);
+    stage_commit<EPB>(sb, lds, n, tid);
   }
   __syncthreads();
 
   constexpr bool ADV_OUT = (OP == OP_RESET || OP == OP_STEP_ADV || OP == OP_READ_ENC);
-  float z[52];
-  bool done = false;
-  if (lane < n && OP != OP_READ_ENC) {
-    Env e = make_env(as_lds(lds + lane * LP), a.seed[env]);
+  if (tid < n && OP != OP_READ_ENC) {
+    const int env = env_of[tid];
+    Env e = make_env(as_lds(lds + tid * LP), a.seed[env]);
     Metrics m = a.met[env];
-    float* zp = (ADV_OUT && a.adv.random_z) ? z : nullptr;
+    bool done = false;
     if (OP == OP_RESET) {
-      env_reset(e, p, m, zp);
+      env_reset(e, p, m, nullptr);                  // random_z floats are produced cooperatively below
       e.elapsed = 0;                                // TimeLimit.reset (time_limit.py:35-37)
       e.ep_ret = 0.f; e.ep_len = 0;                 // VecMonitor.reset (vec_monitor.py:36-40)
     } else if (OP == OP_STEP_ADV) {
-      done = env_step_adversary(e, p, m, a.loc[env], zp);
+      done = env_step_adversary(e, p, m, a.loc[env], nullptr);
     } else if (OP == OP_RESET_AGENT) {
       reset_agent(e);
       e.elapsed = 0;                                // time_limit.py:47-49
@@ -332,27 +363,33 @@ __global__ void __launch_bounds__(WAVE) mg_level_kernel(Params p, LevelArgs a) {
     a.met[env] = m;
     raise(a.errs, e.err, env);
     if (ADV_OUT) {
+      zctr[tid] = e.ctr() - 13;                     // generate_random_z consumed the last 13 counters
       if (a.adv.time_step) a.adv.time_step[env] = (float)e.sb(6);
-      if (a.adv.random_z) for (int k = 0; k < p.random_z_dim; ++k) a.adv.random_z[(size_t)env * p.random_z_dim + k] = z[k];
       if (a.adv_done) a.adv_done[env] = done ? 1 : 0;
     }
   }
   __syncthreads();
-  if (OP != OP_READ_ENC) stage_out(lds, a.rec, env_of, n, lane);
+  if (OP != OP_READ_ENC) stage_out(lds, a.rec, [&](int r) { return env_of[r]; }, n, tid);
   if (ADV_OUT) {
-    // full-grid observation, [x][y][c] u8 and CHW fp32/10 — contiguous per workgroup (identity rows only)
-    const int G = S * S * 3;
+    if (OP != OP_READ_ENC && a.adv.random_z) {
+      // generate_random_z (adversarial.py:449-450): (row, q) pairs, one Philox block = 4 floats each
+      for (int j = tid; j < n * 13; j += NT) {
+        const int r = j / 13, q = j - r * 13, env = env_of[r];
+        uint32_t o[4];
+        philox4x32_10(zctr[r] + q, 0, 0, 0, a.seed[env], p.engine_seed, o);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int k = q * 4 + w;
+          if (k < p.random_z_dim) a.adv.random_z[(size_t)env * p.random_z_dim + k] = (float)(o[w] >> 8) * (1.0f / 16777216.0f);
+        }
+      }
+    }
     uint8_t* u8 = (OP == OP_READ_ENC) ? a.enc_out : a.adv.image_u8;
-    if (u8) for (int f = lane; f < n * G; f += WAVE) {
-      const int r = f / G, el = f - r * G, cell = el / 3, c = el - cell * 3, x = cell / S, y = cell - x * S;
-      u8[(size_t)row0 * G + f] = (uint8_t)(lut.enc[lds[r * LP + y * ROW + x]] >> (8 * c));
-    }
-    if (OP != OP_READ_ENC && a.adv.image_f32) for (int f = lane; f < n * G; f += WAVE) {
-      const int r = f / G, el = f - r * G, c = el / (S * S), cell = el - c * S * S, x = cell / S, y = cell - x * S;
-      a.adv.image_f32[(size_t)row0 * G + f] = lut.div10[(lut.enc[lds[r * LP + y * ROW + x]] >> (8 * c)) & 15];
-    }
+    float* f32 = (OP == OP_READ_ENC) ? nullptr : a.adv.image_f32;
+    if (S == 15) emit_grid<15>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
+    else emit_grid<0>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
   } else {
-    render_emit_v(lds, lut, a.stu, (size_t)row0, n, S, p.V, lane);
+    render_emit_v<EPB>(lds, lut, a.stu, (size_t)row0, n, S, p.V, tid);
   }
 }
 
@@ -459,7 +496,11 @@ static LevelArgs base_args(DcdMg* h) {
 }
 template <int OP> static int launch_level(DcdMg* h, const LevelArgs& a, void* stream) {
   if (a.n_rows <= 0) return 0;
-  hipLaunchKernelGGL(mg_level_kernel<OP>, dim3(nblk(a.n_rows)), dim3(WAVE), 0, (hipStream_t)stream, h->p, a);
+  const int epb = step_epb(a.n_rows);
+  const dim3 grid((a.n_rows + epb - 1) / epb), block(NT);
+  if (epb == 16) hipLaunchKernelGGL((mg_level_kernel<OP, 16>), grid, block, 0, (hipStream_t)stream, h->p, a);
+  else if (epb == 32) hipLaunchKernelGGL((mg_level_kernel<OP, 32>), grid, block, 0, (hipStream_t)stream, h->p, a);
+  else hipLaunchKernelGGL((mg_level_kernel<OP, 64>), grid, block, 0, (hipStream_t)stream, h->p, a);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -590,7 +631,7 @@ int dcd_mg_step(DcdMg* h, const int64_t* actions, int32_t flags, const DcdStepOu
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) { e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1]; h->ev_used += 2; }
   const int epb = step_epb(h->p.B);
-  const dim3 grid((h->p.B + epb - 1) / epb), block(WAVE);
+  const dim3 grid((h->p.B + epb - 1) / epb), block(NT);
   if (epb == 16) hipExtLaunchKernelGGL((mg_step_kernel<false, 16>), grid, block, 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
   else if (epb == 32) hipExtLaunchKernelGGL((mg_step_kernel<false, 32>), grid, block, 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
   else hipExtLaunchKernelGGL((mg_step_kernel<false, 64>), grid, block, 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
@@ -639,7 +680,7 @@ int dcd_mg_step_random(DcdMg* h, uint32_t action_seed, uint32_t t0, int32_t K, i
   a.n_episodes = reinterpret_cast<unsigned long long*>(n_episodes);
   if (out) a.out = *out;
   const int epb = step_epb(h->p.B);
-  const dim3 grid((h->p.B + epb - 1) / epb), block(WAVE);
+  const dim3 grid((h->p.B + epb - 1) / epb), block(NT);
   if (epb == 16) hipLaunchKernelGGL((mg_step_kernel<true, 16>), grid, block, 0, (hipStream_t)stream, h->p, a);
   else if (epb == 32) hipLaunchKernelGGL((mg_step_kernel<true, 32>), grid, block, 0, (hipStream_t)stream, h->p, a);
   else hipLaunchKernelGGL((mg_step_kernel<true, 64>), grid, block, 0, (hipStream_t)stream, h->p, a);

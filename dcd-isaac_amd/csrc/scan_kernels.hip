@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int SCAN_BLOCK = 64;
-constexpr int UNROLL = 8;
+constexpr int UNROLL = 32;   // time steps whose loads are in flight ahead of the dependent chain (one wave per CU at B=4096)
 
 // compute_gae_returns (algos/storage.py:249-256)
 __global__ void __launch_bounds__(SCAN_BLOCK) gae_kernel(const float* __restrict__ rew, const float* __restrict__ val,
@@ -77,11 +77,17 @@ __global__ void __launch_bounds__(SCAN_BLOCK) value_loss_kernel(const float* __r
   const int b = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   if (b >= B) return;
   double acc = 0.0;
-  for (int t = 0; t < T; ++t) {
-    float td = ret[(size_t)t * B + b] - val[(size_t)t * B + b];
-    if (mode == 0) td = fabsf(td); else if (mode == 2) td = td > 0.f ? td : 0.f;
-    if (power > 1) { float pw = td; for (int k = 1; k < power; ++k) pw = pw * td; td = pw; }
-    acc += (double)td;
+  for (int t0 = 0; t0 < T; t0 += UNROLL) {
+    float r[UNROLL], v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) { const bool in = t0 + u < T; r[u] = in ? ret[(size_t)(t0 + u) * B + b] : 0.f; v[u] = in ? val[(size_t)(t0 + u) * B + b] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) if (t0 + u < T) {
+      float td = r[u] - v[u];
+      if (mode == 0) td = fabsf(td); else if (mode == 2) td = td > 0.f ? td : 0.f;
+      if (power > 1) { float pw = td; for (int k = 1; k < power; ++k) pw = pw * td; td = pw; }
+      acc += (double)td;
+    }
   }
   float m = (float)(acc / (double)T);
   if (clipped) m = m < -1.f ? -1.f : (m > 1.f ? 1.f : m);
@@ -93,10 +99,12 @@ __global__ void __launch_bounds__(SCAN_BLOCK) seg_count_kernel(const float* __re
   const int b = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   if (b >= B) return;
   int n = 0, start_t = 0;
-  for (int t = 1; t <= T; ++t) {                 // a done at t == 0 is skipped (:504-505)
-    if (msk[(size_t)t * B + b] > 0.f) continue;
-    if (!(start_t < T)) break;
-    ++n; start_t = t;
+  for (int t0 = 1; t0 <= T; t0 += UNROLL) {        // a done at t == 0 is skipped (:504-505)
+    float m[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) m[u] = (t0 + u <= T) ? msk[(size_t)(t0 + u) * B + b] : 1.f;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) if (!(m[u] > 0.f) && start_t < T) { ++n; start_t = t0 + u; }
   }
   if (start_t < T) ++n;                          // trailing partial segment (:551)
   counts[b] = n;
@@ -145,83 +153,86 @@ struct ScoreArgs {
   DcdEpisodeRec* recs; int max_recs; const int* offsets;
 };
 
-// score functions (level_sampler.py:275-349, 426-439); fp64 accumulation of fp32 terms, one rounding
-__device__ void score_segment(const ScoreArgs& a, int b, int s, int e, float* mean_out, float* max_out, float* rsum_out) {
-  const int B = a.B, L = e - s;
-  double acc = 0.0, rs = 0.0;
-  float mx = -INFINITY;
-  for (int t = s; t < e; ++t) rs += (double)a.rew[(size_t)t * B + b];
-  *rsum_out = (float)rs;
-  const int st = a.strategy;
-  if (st == DCD_SCORE_UNIFORM) { *mean_out = 1.f; *max_out = 1.f; return; }
-  if (st == DCD_SCORE_RETURN_SUM) { *mean_out = 0.f; *max_out = 0.f; return; }
-  if (st == DCD_SCORE_ONE_STEP_TD) {
-    if (L > 1) {
-      for (int t = s; t < e - 1; ++t) {
-        const float td = fabsf((a.rew[(size_t)t * B + b] + (a.g * a.val[(size_t)(t + 1) * B + b])) - a.val[(size_t)t * B + b]);
-        acc += td; mx = td > mx ? td : mx;
-      }
-      *mean_out = (float)(acc / (double)(L - 1)); *max_out = mx;
-    } else { const float td = a.rew[(size_t)s * B + b] - a.val[(size_t)s * B + b]; *mean_out = td; *max_out = td; }
-    return;
+// Single pass over t per env (one env per lane): every step's loads are issued CH steps ahead, the
+// per-segment accumulators (fp64 sum of fp32 terms in step order, fp32 max) are flushed into a record
+// whenever masks[t+1] == 0.  Same accumulation order as oracle/scan_oracle.c -> bit-identical records.
+// score functions: level_sampler.py:275-349, 426-439.
+struct SegAcc {
+  double acc, rs; float mx, mn; float r0, v0; int start;
+  __device__ __forceinline__ void reset(int s) { acc = 0.0; rs = 0.0; mx = -INFINITY; mn = INFINITY; r0 = 0.f; v0 = 0.f; start = s; }
+};
+
+__device__ __forceinline__ void flush_segment(const ScoreArgs& a, int b, SegAcc& sg, int end, int flags, int& k) {
+  const int L = end - sg.start, st = a.strategy;
+  if (k < a.max_recs) {
+    DcdEpisodeRec r;
+    r.actor = b; r.seed = a.seeds[(size_t)sg.start * a.B + b]; r.start_t = sg.start; r.num_steps = L; r.flags = flags;
+    r.reward_sum = (float)sg.rs;
+    if (st == DCD_SCORE_UNIFORM) { r.mean_score = 1.f; r.max_score = 1.f; }
+    else if (st == DCD_SCORE_RETURN_SUM) { r.mean_score = 0.f; r.max_score = 0.f; }
+    else if (st == DCD_SCORE_ONE_STEP_TD) {
+      if (L > 1) { r.mean_score = (float)(sg.acc / (double)(L - 1)); r.max_score = sg.mx; }
+      else { r.mean_score = sg.r0 - sg.v0; r.max_score = r.mean_score; }                  // signed (:433)
+    } else if (st == DCD_SCORE_MIN_MARGIN) {                                              // 1 - mean, 1 - min (:302-303)
+      r.mean_score = (float)(1.0 - (double)(float)(sg.acc / (double)L)); r.max_score = (float)(1.0 - (double)sg.mn);
+    } else { r.mean_score = (float)(sg.acc / (double)L); r.max_score = sg.mx; }
+    a.recs[k] = r;
   }
-  if (st == DCD_SCORE_POLICY_ENTROPY || st == DCD_SCORE_LEAST_CONFIDENCE || st == DCD_SCORE_MIN_MARGIN) {
-    float ls[64];
-    float mn = INFINITY;
-    const int A = a.A;
-    const float max_entropy = (float)log((double)A);
-    for (int t = s; t < e; ++t) {
-      log_softmax(a.logits + ((size_t)t * B + b) * A, A, ls);
-      float v;
-      if (st == DCD_SCORE_POLICY_ENTROPY) {
-        float h = 0.f;
-        for (int k = 0; k < A; ++k) h += -expf(ls[k]) * ls[k];
-        v = h / max_entropy;
-      } else if (st == DCD_SCORE_LEAST_CONFIDENCE) {
-        float m = ls[0];
-        for (int k = 1; k < A; ++k) m = ls[k] > m ? ls[k] : m;
-        v = 1.f - expf(m);
-      } else {
-        float m1 = -INFINITY, m2 = -INFINITY;
-        for (int k = 0; k < A; ++k) { if (ls[k] > m1) { m2 = m1; m1 = ls[k]; } else if (ls[k] > m2) m2 = ls[k]; }
-        v = expf(m1) - expf(m2);
-      }
-      acc += v; mx = v > mx ? v : mx; mn = v < mn ? v : mn;
-    }
-    if (st == DCD_SCORE_MIN_MARGIN) { *mean_out = (float)(1.0 - (double)(float)(acc / (double)L)); *max_out = (float)(1.0 - (double)mn); }
-    else { *mean_out = (float)(acc / (double)L); *max_out = mx; }
-    return;
-  }
-  for (int t = s; t < e; ++t) {
-    float adv = a.ret[(size_t)t * B + b] - a.val[(size_t)t * B + b];
-    if (st == DCD_SCORE_VALUE_L1) adv = fabsf(adv);
-    else if (st == DCD_SCORE_POSITIVE_VALUE_LOSS) adv = adv > 0.f ? adv : 0.f;
-    acc += adv; mx = adv > mx ? adv : mx;
-  }
-  *mean_out = (float)(acc / (double)L); *max_out = mx;
+  ++k;
 }
 
 __global__ void __launch_bounds__(SCAN_BLOCK) seg_score_kernel(ScoreArgs a) {
+  constexpr int CH = 16;
   const int b = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   if (b >= a.B) return;
-  const int T = a.T, B = a.B;
-  int k = a.offsets[b], start_t = 0;
-  for (int t = 1; t <= T + 1; ++t) {
-    const bool tail = (t == T + 1);
-    if (!tail) { if (a.msk[(size_t)t * B + b] > 0.f) continue; }
-    if (!(start_t < T)) break;
-    const int end = tail ? T : t;
-    if (k < a.max_recs) {
-      DcdEpisodeRec r;
-      r.actor = b; r.seed = a.seeds[(size_t)start_t * B + b]; r.start_t = start_t; r.num_steps = end - start_t;
-      r.flags = tail ? 0 : (1 | ((a.cliff[(size_t)t * B + b] > 0.f) ? 0 : 2));
-      score_segment(a, b, start_t, end, &r.mean_score, &r.max_score, &r.reward_sum);
-      a.recs[k] = r;
+  const int T = a.T, B = a.B, st = a.strategy, A = a.A;
+  const bool use_ret = st <= DCD_SCORE_SIGNED_VALUE_LOSS, use_logits = st == DCD_SCORE_POLICY_ENTROPY || st == DCD_SCORE_LEAST_CONFIDENCE || st == DCD_SCORE_MIN_MARGIN;
+  const bool use_val = use_ret || st == DCD_SCORE_ONE_STEP_TD;
+  const float max_entropy = (float)log((double)(A > 0 ? A : 1));
+  int k = a.offsets[b];
+  SegAcc sg; sg.reset(0);
+  float vnext = use_val ? a.val[b] : 0.f;                  // v[t] carried across chunks (TD needs v[t+1])
+  for (int t0 = 0; t0 < T; t0 += CH) {
+    float m1[CH], cl[CH], rw[CH], rt[CH], v1[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int t = t0 + u; const bool in = t < T;
+      m1[u] = in ? a.msk[(size_t)(t + 1) * B + b] : 1.f;
+      cl[u] = in ? a.cliff[(size_t)(t + 1) * B + b] : 1.f;
+      rw[u] = in ? a.rew[(size_t)t * B + b] : 0.f;
+      rt[u] = (in && use_ret) ? a.ret[(size_t)t * B + b] : 0.f;
+      v1[u] = (in && use_val) ? a.val[(size_t)(t + 1) * B + b] : 0.f;
     }
-    ++k;
-    if (tail) break;
-    start_t = t;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int t = t0 + u;
+      if (t < T && sg.start < T) {
+        const float v0 = vnext;
+        const bool seg_ends = !(m1[u] > 0.f);                // done at t+1 closes [start, t+1)
+        const bool last_in_seg = seg_ends || t == T - 1;
+        sg.rs += (double)rw[u];
+        if (t == sg.start) { sg.r0 = rw[u]; sg.v0 = v0; }
+        if (use_ret) {
+          float adv = rt[u] - v0;
+          if (st == DCD_SCORE_VALUE_L1) adv = fabsf(adv); else if (st == DCD_SCORE_POSITIVE_VALUE_LOSS) adv = adv > 0.f ? adv : 0.f;
+          sg.acc += adv; sg.mx = adv > sg.mx ? adv : sg.mx;
+        } else if (st == DCD_SCORE_ONE_STEP_TD) {
+          if (!last_in_seg) { const float td = fabsf((rw[u] + (a.g * v1[u])) - v0); sg.acc += td; sg.mx = td > sg.mx ? td : sg.mx; }
+        } else if (use_logits) {
+          float ls[64];
+          log_softmax(a.logits + ((size_t)t * B + b) * A, A, ls);
+          float v;
+          if (st == DCD_SCORE_POLICY_ENTROPY) { float h = 0.f; for (int q = 0; q < A; ++q) h += -expf(ls[q]) * ls[q]; v = h / max_entropy; }
+          else if (st == DCD_SCORE_LEAST_CONFIDENCE) { float m = ls[0]; for (int q = 1; q < A; ++q) m = ls[q] > m ? ls[q] : m; v = 1.f - expf(m); }
+          else { float q1 = -INFINITY, q2 = -INFINITY; for (int q = 0; q < A; ++q) { if (ls[q] > q1) { q2 = q1; q1 = ls[q]; } else if (ls[q] > q2) q2 = ls[q]; } v = expf(q1) - expf(q2); }
+          sg.acc += v; sg.mx = v > sg.mx ? v : sg.mx; sg.mn = v < sg.mn ? v : sg.mn;
+        }
+        if (seg_ends) { flush_segment(a, b, sg, t + 1, 1 | ((cl[u] > 0.f) ? 0 : 2), k); sg.reset(t + 1); }
+      }
+      if (t < T) vnext = v1[u];
+    }
   }
+  if (sg.start < T) flush_segment(a, b, sg, T, 0, k);        // trailing partial segment (:551-578)
 }
 
 // grounded_* strategies (level_sampler.py:351-424), one lane per record
@@ -250,9 +261,12 @@ __global__ void __launch_bounds__(SCAN_BLOCK) return_stats_kernel(const float* _
   const int b = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   if (b >= B) return;
   double acc = 0.0; float mx = -INFINITY; int n = 0;
-  for (int t = 0; t < T; ++t) if (info[(size_t)t * B + b] & DCD_INFO_EPISODE) {
-    const float r = ep_ret[(size_t)t * B + b];
-    acc += r; mx = r > mx ? r : mx; ++n;
+  for (int t0 = 0; t0 < T; t0 += UNROLL) {
+    float r[UNROLL]; uint8_t f[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) { const bool in = t0 + u < T; f[u] = in ? info[(size_t)(t0 + u) * B + b] : 0; r[u] = in ? ep_ret[(size_t)(t0 + u) * B + b] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) if (f[u] & DCD_INFO_EPISODE) { acc += r[u]; mx = r[u] > mx ? r[u] : mx; ++n; }
   }
   mean_r[b] = n ? (float)(acc / (double)n) : 0.f;
   max_r[b] = n ? mx : 0.f;
