@@ -108,6 +108,7 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
         code[i] = (ax == NOPOS) ? 64 : c;                      // 64: no agent placed yet -> zero observation
       }
     }
+    __builtin_amdgcn_sched_barrier(0);                       // keep the gathers batched ahead of the LUT/store phase
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {                         // phase 2: LUT + stores
       const int q = i * NT + tid, row = q / VV, ci = q - row * VV;
