@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-work budget of the cpu_baseline leg")
     ap.add_argument("--sweep", action="store_true", help="also time dcd_mg_step alone at large B (roofline sweep)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a shared GPU)")
     return ap.parse_args()
 
 
@@ -154,7 +155,7 @@ def cpu_baseline(B, T, budget_s):
     out, st = m.step_buffers()
     rolls, steps, t_used = 0, 0, 0.0
     with ThreadPoolExecutor(nt) as ex:
-        while t_used * nt < budget_s and rolls < 8:
+        while t_used * nt < budget_s and rolls < 400:
             t0 = time.perf_counter()
             list(ex.map(lambda i: m.rollout_range(st, i * B // nt, (i + 1) * B // nt, T, 3, rolls * T), range(nt)))
             t_used += time.perf_counter() - t0
@@ -218,13 +219,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU mode")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()          # (ranks share a GPU only in gloo rehearsals)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     B, T = args.envs, args.num_steps
     ps = PairedPass(B, T, device, rank)
@@ -273,6 +278,10 @@ def main():
         total_steps = ps.steps_per_pass() * world * args.steps
         algo = B * STEP_ALGO_BYTES
         achieved = algo / kernel_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and B == 4096:            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         line = {
             "metric": "env-steps/sec (whole node), MultiGrid PAIRED 4096 envs/GPU",
             "value": total_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -286,7 +295,7 @@ def main():
                        "env_steps_per_pass_per_gpu": ps.steps_per_pass(),
                        "episode_records_last_pass": n_recs, "episodes_last_pass": episodes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "mg_step_kernel<false>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "mg_step_kernel<false,16>",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_us": kernel_s * 1e6,
                          "note": "B=4096 moves 1.76 MB per launch: latency-bound, see DESIGN.md; --sweep adds large-B"},
         }
