@@ -57,6 +57,10 @@ class Conv2d_tf(nn.Conv2d):
 
     def forward(self, x):
         if self._tf_padding == "valid":
+            if x.is_cuda and self.groups == 1 and self.stride == (1, 1) and self.dilation == (1, 1):
+                # no MIOpen on the GPU path: its per-shape kernel build stalls for seconds on every new batch size
+                # (3.9 s per update for the ragged truncated-value batch) and its launch geometry overflows at T*B
+                return self._valid_conv_gemm(x)
             return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
         pads = []
         for dim in (0, 1):
@@ -68,6 +72,29 @@ class Conv2d_tf(nn.Conv2d):
             x = F.pad(x, [0, pads[1] % 2, 0, pads[0] % 2])
         return F.conv2d(x, self.weight, self.bias, self.stride, (pads[0] // 2, pads[1] // 2), self.dilation,
                         self.groups)
+
+
+def _valid_conv_gemm(self, x):
+    """'valid' conv as explicit im2col (kh*kw shifted window slices) + ONE GEMM.  Used for batches beyond
+    MIOpen's launch geometry (the PPO batch is T*B = 1 048 576 images: 'invalid configuration argument')
+    and checked against F.conv2d in tests; F.unfold is avoided (13 ms for 4096 5x5 images on ROCm)."""
+    N, C, H, W = x.shape
+    O, _, kh, kw = self.weight.shape
+    oh, ow = H - kh + 1, W - kw + 1
+    K = C * kh * kw
+    w_t = self.weight.view(O, K).t()
+    outs = []
+    for s in range(0, N, 262144):                                  # bound the im2col workspace
+        xs = x[s:s + 262144]
+        n = xs.size(0)
+        cols = torch.stack([xs[:, :, i:i + oh, j:j + ow] for i in range(kh) for j in range(kw)], dim=2)  # [n,C,kh*kw,oh,ow]
+        a = cols.permute(0, 3, 4, 1, 2).reshape(n * oh * ow, K)      # rows: (image, out cell); cols: (c, ki, kj)
+        y = torch.addmm(self.bias, a, w_t) if self.bias is not None else a @ w_t
+        outs.append(y.view(n, oh * ow, O).transpose(1, 2).reshape(n, O, oh, ow))
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
+Conv2d_tf._valid_conv_gemm = _valid_conv_gemm
 
 
 class RNN(nn.Module):
@@ -98,8 +125,39 @@ class RNN(nn.Module):
     def output_size(self):
         return self._hidden_size
 
+    def _lstm_cuda(self, x, hxs, masks, single_step):
+        """Masked LSTM with explicit GEMMs + pointwise ops (no MIOpen RNN: see _valid_conv_gemm).  The state is
+        multiplied by masks[t] before EVERY step, which equals the reference's chunking (inside a chunk the
+        masks are all ones, common.py:157-207); the input projection of all T steps is one GEMM."""
+        r = self.rnn
+        H = self._hidden_size
+        h, c = hxs
+        if single_step:
+            gates = torch.addmm(r.bias_ih_l0 + r.bias_hh_l0, x, r.weight_ih_l0.t()) + (h * masks) @ r.weight_hh_l0.t()
+            i, f, g, o = gates.split(H, dim=1)
+            c = torch.sigmoid(f) * (c * masks) + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            return h, (h, c)
+        N = h.size(0)
+        T = x.size(0) // N
+        # unbind (ONE UnbindBackward that stacks the per-step grads) — indexing xp[t] in the loop would make
+        # every step's backward materialise a full [T,N,4H] zero tensor (4.3 GB at T=256, N=4096)
+        xp = torch.addmm(r.bias_ih_l0 + r.bias_hh_l0, x, r.weight_ih_l0.t()).view(T, N, 4 * H).unbind(0)
+        m = masks.view(T, N, 1).unbind(0)
+        w_hh_t = r.weight_hh_l0.t()
+        outs = []
+        for t in range(T):
+            h, c = h * m[t], c * m[t]
+            i, f, g, o = (xp[t] + h @ w_hh_t).split(H, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            outs.append(h)
+        return torch.stack(outs, 0).view(T * N, H), (h, c)
+
     def forward(self, x, hxs, masks):
         n_state = hxs[0].size(0) if self.is_lstm else hxs.size(0)
+        if self.is_lstm and x.is_cuda:
+            return self._lstm_cuda(x, hxs, masks, x.size(0) == n_state)
         if x.size(0) == n_state:                                   # one step
             state = tuple((h * masks).unsqueeze(0) for h in hxs) if self.is_lstm else (hxs * masks).unsqueeze(0)
             y, state = self.rnn(x.unsqueeze(0), state)

@@ -134,3 +134,25 @@ def test_ppo_update_matches_reference():
 def test_lz_complexity_and_agent_facade():
     from algos.storage import lempel_ziv_complexity
     assert lempel_ziv_complexity("") == 0 and lempel_ziv_complexity("aaaa") == 2 and lempel_ziv_complexity("abab") == 3
+
+
+def test_gemm_conv_and_manual_lstm_formulas_match_torch_modules():
+    """The CUDA-path formulas (im2col GEMM conv, explicit masked LSTM) evaluated on CPU tensors equal the
+    nn.Conv2d / nn.LSTM path the reference uses (fp32 tolerance)."""
+    from models.common import Conv2d_tf, RNN
+    torch.manual_seed(0)
+    conv = Conv2d_tf(3, 16, kernel_size=3, stride=1, padding="valid")
+    x = torch.rand(37, 3, 5, 5)
+    np.testing.assert_allclose(conv._valid_conv_gemm(x).detach().numpy(), conv(x).detach().numpy(), rtol=1e-5, atol=1e-6)
+    rnn = RNN(149, 256, "lstm")
+    T, N = 9, 5
+    xs = torch.randn(T * N, 149)
+    masks = (torch.rand(T * N, 1) > 0.3).float()
+    h0 = (torch.randn(N, 256), torch.randn(N, 256))
+    y_ref, s_ref = rnn(xs, h0, masks)
+    y, s = rnn._lstm_cuda(xs, h0, masks, single_step=False)
+    np.testing.assert_allclose(y.detach().numpy(), y_ref.detach().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(s[1].detach().numpy(), s_ref[1].detach().numpy(), rtol=1e-5, atol=2e-6)
+    y1_ref, _ = rnn(xs[:N], h0, masks[:N])
+    y1, _ = rnn._lstm_cuda(xs[:N], h0, masks[:N], single_step=True)
+    np.testing.assert_allclose(y1.detach().numpy(), y1_ref.detach().numpy(), rtol=1e-5, atol=2e-6)
