@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-work budget of the cpu_baseline leg")
     ap.add_argument("--sweep", action="store_true", help="also time dcd_mg_step alone at large B (roofline sweep)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a shared GPU)")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the end-to-end PAIRED leg (policy nets + PPO in the loop)")
+    ap.add_argument("--train-updates", type=int, default=2, help="timed AdversarialRunner.run() calls of the end-to-end leg")
     return ap.parse_args()
 
 
@@ -209,6 +211,41 @@ def sweep_large_b(device, sizes=(65536, 1048576), iters=30):
     return res
 
 
+def end_to_end_leg(B, T, device, updates):
+    """SURVEY §8d S_roll / S_train: the same PAIRED config with the PyTorch policy/value nets and PPO in the
+    loop (AdversarialRunner.run(): teacher rollout, 2 student rollouts, 3 PPO updates of 5 epochs).  Reported
+    beside the headline value, never as it: this leg is dominated by PyTorch, not by the HIP kernels."""
+    from arguments import parser as arg_parser
+    from envs.runners import AdversarialRunner
+    from util import create_parallel_env, make_agent, seed
+    a = arg_parser.parse_args([])
+    for k, v in dict(env_name="MultiGrid-GoalLastFewerBlocksAdversarial-v0", num_processes=B, num_steps=T, ued_algo="paired",
+                     handle_timelimits=True, recurrent_adversary_env=True, ppo_epoch=5, adv_ppo_epoch=5, num_mini_batch=1).items():
+        setattr(a, k, v)
+    seed(1)
+    venv, ued = create_parallel_env(a, device=device)
+    agents = [make_agent(n, venv, a, device) for n in ("agent", "adversary_agent", "adversary_env")]
+    runner = AdversarialRunner(args=a, venv=venv, agent=agents[0], ued_venv=ued, adversary_agent=agents[1],
+                               adversary_env=agents[2], train=True, device=device)
+    runner.run()                                                  # warm-up (allocator, GEMM heuristics)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        runner.run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / updates
+    t0 = time.perf_counter()
+    runner._student_rollout(agents[0], T, False, None, {})
+    torch.cuda.synchronize()
+    roll = time.perf_counter() - t0
+    venv.close()
+    return {"S_roll_env_steps_per_s": B * T / roll, "student_rollout_ms": roll * 1e3,
+            "S_train_sps_reference_formula": B * T / dt,                    # train.py:184 counts one student rollout per update
+            "S_train_true_env_steps_per_s": (2 * B * T + B * 27) / dt, "seconds_per_update": dt, "updates_timed": updates,
+            "what": "AdversarialRunner.run(), PAIRED, LSTM-256 students (433 953 params) + recurrent teacher (22 502 732 params), "
+                    "PPO 5 epochs x 1 minibatch, fp32, eager PyTorch-ROCm"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -303,6 +340,10 @@ def main():
             line["roofline_large_b"] = sweep
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, T, args.cpu_seconds)
+        if not args.no_train_leg and world == 1:
+            del ps                                                    # free the 2 GB of benchmark buffers first
+            torch.cuda.empty_cache()
+            line["end_to_end"] = end_to_end_leg(B, T, device, args.train_updates)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -100,6 +100,14 @@ class AdversarialRunner:
         B = args.num_processes
         self._done_buf = torch.zeros(B, dtype=torch.uint8, device=self.device)
         self._seeds_dev = torch.full((B, 1), -1, dtype=torch.int32, device=self.device)
+        # HIP graphs (opt-in, DCD_HIP_GRAPHS=1): a rollout (policy forward + sampling + env step + storage
+        # writes) captured in chunks of GRAPH_CHUNK steps and replayed — the inner loop is launch-bound (~40
+        # small kernels per step).  OFF by default: with the PyTorch nets inside, capture/instantiate on
+        # ROCm 7.2 took minutes at B=4096 (the engine-only graph of bench.py, ~1.1k kernel nodes, is fine).
+        # Replay rollouts that re-sample levels on the host per step always stay eager.
+        import os
+        self.use_hip_graphs = os.environ.get("DCD_HIP_GRAPHS", "0") == "1" and self.device.type == "cuda"
+        self._graphs = {}
 
     # ---- bookkeeping ---------------------------------------------------------------------------
     @property
@@ -250,11 +258,43 @@ class AdversarialRunner:
         return self._default_level_sampler.sample_replay_decision()
 
     # ---- rollouts --------------------------------------------------------------------------------
+    GRAPH_CHUNK = 32          # rollout steps per HIP graph (~1.4k kernel nodes; 10k-node graphs proved unstable)
+
+    def _graphed(self, key, num_steps, fn):
+        """fn(t0, t1) issues rollout steps [t0, t1).  First call: eager (warm-up); second: captured into one
+        HIP graph per GRAPH_CHUNK steps and replayed; afterwards: replay only."""
+        if not self.use_hip_graphs:
+            return fn(0, num_steps)
+        state = self._graphs.get(key)
+        if state is None:
+            fn(0, num_steps)
+            self._graphs[key] = "warm"
+            return
+        if state == "warm":
+            torch.cuda.synchronize()
+            state = []
+            for t0 in range(0, num_steps, self.GRAPH_CHUNK):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fn(t0, min(t0 + self.GRAPH_CHUNK, num_steps))
+                state.append(g)
+            self._graphs[key] = state
+        for g in state:
+            g.replay()
+
     def _teacher_rollout(self, agent, num_steps):
-        """Constructive teacher episode (:481, :497-592 with is_env=True)."""
+        self._graphed(("teacher", id(agent), num_steps, bool(agent.actor_critic.random)), num_steps,
+                      lambda t0, t1: self._teacher_rollout_body(agent, t0, t1))
+        agent.storage.step = 0
+        self.ued_venv.raise_errors()
+
+    def _teacher_rollout_body(self, agent, t0, t1):
+        """Constructive teacher episode, steps [t0, t1) (:481, :497-592 with is_env=True)."""
         st, venv, B = agent.storage, self.ued_venv, self.args.num_processes
-        venv.reset_device(st.adversary_obs_out(0))
-        for step in range(num_steps):
+        if t0 == 0:
+            venv.reset_device(st.adversary_obs_out(0))
+        st.step = t0
+        for step in range(t0, t1):
             with torch.no_grad():
                 value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step),
                                                          st.masks[step])
@@ -268,7 +308,6 @@ class AdversarialRunner:
             st.bad_masks[step + 1].fill_(1.0)
             st.cliffhanger_masks[step + 1].fill_(1.0)
             st.advance()
-        venv.raise_errors()
 
     def _resample_finished_levels(self, st, step, level_sampler, rollout_info):
         """PLR replay rollouts: every env that finished an episode gets a new replay level
@@ -293,13 +332,26 @@ class AdversarialRunner:
             rollout_info["solved_idx"][i] = True
 
     def _student_rollout(self, agent, num_steps, level_replay, level_sampler, rollout_info):
-        args, st, venv = self.args, agent.storage, self.venv
-        reset_random = self.is_dr and not args.use_plr
-        venv.reset_agent_device(st.student_obs_out(0))
         track_seeds = level_sampler is not None
         if track_seeds:
             self._seeds_dev.copy_(torch.tensor(self.current_level_seeds, dtype=torch.int32).view(-1, 1))
-        for step in range(num_steps):
+        host_resampling = level_sampler is not None and level_replay
+        body = lambda t0, t1: self._student_rollout_body(agent, num_steps, t0, t1, level_replay, level_sampler, rollout_info)
+        if host_resampling:
+            body(0, num_steps)
+        else:
+            self._graphed(("student", id(agent), num_steps, track_seeds, bool(agent.actor_critic.random)), num_steps, body)
+        agent.storage.step = 0
+        self.venv.raise_errors()
+
+    def _student_rollout_body(self, agent, num_steps, t0, t1, level_replay, level_sampler, rollout_info):
+        args, st, venv = self.args, agent.storage, self.venv
+        reset_random = self.is_dr and not args.use_plr
+        if t0 == 0:
+            venv.reset_agent_device(st.student_obs_out(0))
+        st.step = t0
+        track_seeds = level_sampler is not None
+        for step in range(t0, t1):
             with torch.no_grad():
                 value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step),
                                                          st.masks[step])
@@ -318,7 +370,6 @@ class AdversarialRunner:
                 self.current_level_seeds = self._next_level_seeds
                 self._seeds_dev.copy_(torch.tensor(self.current_level_seeds, dtype=torch.int32).view(-1, 1))
             st.advance()
-        venv.raise_errors()
 
     def agent_rollout(self, agent, num_steps, update=False, is_env=False, level_replay=False, level_sampler=None,
                       update_level_sampler=False, discard_grad=False, edit_level=False, num_edits=0, fixed_seeds=None):

@@ -22,4 +22,5 @@ class Categorical(nn.Module):
         nn.init.constant_(self.linear.bias.data, 0)
 
     def forward(self, x):
-        return FixedCategorical(logits=self.linear(x))
+        # validate_args=False: the constraint check synchronises the stream (and is illegal inside HIP-graph capture)
+        return FixedCategorical(logits=self.linear(x), validate_args=False)

@@ -47,7 +47,3 @@ ts = teacher.storage
 nv = teacher.get_value(ts.get_obs(-1), ts.get_recurrent_hidden_state(-1), ts.masks[-1]).detach()
 ts.compute_returns(nv, True, 0.995, 0.95)
 timed("teacher PPO update (5 epochs)", lambda: teacher.update())
-with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA]) as p:
-    runner._student_rollout(agent, 256, False, None, {}); st.compute_returns(nv[:B] if nv.shape[0] != B else agent.get_value(st.get_obs(-1), st.get_recurrent_hidden_state(-1), st.masks[-1]).detach(), True, 0.995, 0.95)
-    agent.algo.ppo_epoch = 1; agent.update(); sync()
-print(p.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=60))
