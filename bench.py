@@ -338,7 +338,7 @@ def main():
         }
         if sweep is not None:
             line["roofline_large_b"] = sweep
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(B, T, args.cpu_seconds)
         if not args.no_train_leg and world == 1:
             del ps                                                    # free the 2 GB of benchmark buffers first
