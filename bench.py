@@ -169,6 +169,36 @@ def cpu_baseline(B, T, budget_s):
                        f"{t_used:.1f}s wall, full StepOut incl. fp32 obs)")
 
 
+def py_subproc_baseline(seconds=3.0):
+    """Second CPU stand-in: the reference-SHAPED path — pure-Python object-per-cell MultiGrid, one
+    worker process per env, pickled tuples over pipes, auto-reset (oracle/py_multigrid.py; checked against the
+    C oracle in tests/test_py_multigrid.py).  min(32, cores) workers as the reference's default num_processes."""
+    from oracle.py_multigrid import PySubprocVecEnv
+    cores = len(os.sched_getaffinity(0))
+    n = max(1, min(32, cores))
+    rng = np.random.default_rng(0)
+    enc = np.zeros((n, 15, 15, 3), np.uint8)
+    enc[..., 0] = 1
+    enc[:, 0, :], enc[:, -1, :], enc[:, :, 0], enc[:, :, -1] = (2, 5, 0), (2, 5, 0), (2, 5, 0), (2, 5, 0)
+    for b in range(n):
+        cells = rng.permutation(169)[:27]
+        for k, c in enumerate(cells):
+            x, y = c % 13 + 1, c // 13 + 1
+            enc[b, x, y] = (8, 1, 0) if k == 0 else ((10, 0, 0) if k == 1 else (2, 5, 0))
+    v = PySubprocVecEnv(n)
+    try:
+        v.set_levels(enc, rng.integers(0, 4, n))
+        steps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            v.step_env(rng.integers(0, 7, n))
+            steps += n
+        dt = time.perf_counter() - t0
+    finally:
+        v.close()
+    return dict(value=steps / dt, unit="env-steps/s", cores=n, kind="port",
+                sample=f"{steps} steps, {n} worker processes x 1 env, pure-Python object-per-cell MultiGrid over pipes, {dt:.1f}s wall")
+
+
 def step_kernel_profile(ps, n=256):
     """Average duration of the dominant kernel (mg_step_kernel) from HIP events attached to each
     dispatch, on torch's current stream, over one eager student rollout of the benchmark workload."""
@@ -340,6 +370,7 @@ def main():
             line["roofline_large_b"] = sweep
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(B, T, args.cpu_seconds)
+            line["cpu_baseline_py_subproc"] = py_subproc_baseline()
         if not args.no_train_leg and world == 1:
             del ps                                                    # free the 2 GB of benchmark buffers first
             torch.cuda.empty_cache()
