@@ -284,6 +284,9 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # The worker processes of the py-subproc stand-in are forked BEFORE this process touches the GPU
+    # (no fork/exec from a HIP-initialised process).
+    py_base = py_subproc_baseline() if (world == 1 and not args.no_cpu_baseline) else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU mode")
     dev_index = local_rank % torch.cuda.device_count()          # (ranks share a GPU only in gloo rehearsals)
@@ -370,7 +373,7 @@ def main():
             line["roofline_large_b"] = sweep
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(B, T, args.cpu_seconds)
-            line["cpu_baseline_py_subproc"] = py_subproc_baseline()
+            line["cpu_baseline_py_subproc"] = py_base
         if not args.no_train_leg and world == 1:
             del ps                                                    # free the 2 GB of benchmark buffers first
             torch.cuda.empty_cache()
