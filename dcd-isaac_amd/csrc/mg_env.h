@@ -360,20 +360,32 @@ DCD_HD bool env_step_adversary(Env& e, const Params& p, Metrics& m, int64_t loc,
   return done;
 }
 
-// reset_to_encoding body after reset() (adversarial.py:290-294; multigrid.py:264-280)
-DCD_HD void env_set_encoding(Env& e, const Params& p, Metrics& m, const uint8_t* enc) {
+// reset_to_encoding body after reset() (adversarial.py:290-294; multigrid.py:264-280).
+// keep_dir: fixed-level families (MazeEnv._gen_grid, maze.py:76-94) take the start direction from the
+// encoding's agent cell instead of the random draw of AdversarialEnv.reset.
+DCD_HD void env_set_encoding(Env& e, const Params& p, Metrics& m, const uint8_t* enc, bool keep_dir = false) {
   const int S = p.S;
   for (int i = 0; i < S; ++i) for (int j = 0; j < S; ++j) {
     const uint8_t* c = enc + (i * S + j) * 3;
     uint8_t code;
     if (!dec3(c[0], c[1], c[2], &code)) { e.err |= DCD_ERR_BAD_ENCODING; code = C_NONE; }
-    if (is_agent(code)) { e.sb(0) = (uint8_t)i; e.sb(1) = (uint8_t)j; }
+    if (is_agent(code)) { e.sb(0) = (uint8_t)i; e.sb(1) = (uint8_t)j; if (keep_dir) e.sb(2) = (uint8_t)(code - C_AGENT0); }
     else if (code == C_GOAL) { e.sb(3) = (uint8_t)i; e.sb(4) = (uint8_t)j; }
     e.cell(i, j) = code;
   }
   e.full_dirty = true;
   compute_metrics(e, p, m);
   reset_agent(e);
+}
+
+// MultiGridEnv.reset of a FIXED level (multigrid.py:470-502 with maze.py:76-94 as _gen_grid): the grid is
+// the given encoding, the agent starts on its cell facing the encoded direction; no random draw.
+DCD_HD void env_load_fixed_level(Env& e, const Params& p, Metrics& m, const uint8_t* enc) {
+  e.step_count = 0; e.sb(6) = 0;
+  reset_agent_status(e);
+  e.sb(0) = NOPOS; e.sb(3) = NOPOS;
+  reset_metrics(m, p);
+  env_set_encoding(e, p, m, enc, true);
 }
 
 // reset_random (adversarial.py:541-581)

@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(NT) mg_step_kernel(Params p, StepArgs a) {
 
 // =================================================================================== level ops
 enum LevelOp { OP_RESET = 0, OP_STEP_ADV, OP_RESET_AGENT, OP_RESET_RANDOM, OP_SET_ENCODING, OP_REPLAY, OP_MUTATE,
-               OP_READ_ENC };
+               OP_READ_ENC, OP_FIXED_LEVEL };
 
 struct LevelArgs {
   uint8_t* rec; const uint32_t* seed; Metrics* met; uint32_t* errs;
@@ -350,6 +350,10 @@ __global__ void __launch_bounds__(NT) mg_level_kernel(Params p, LevelArgs a) {
       env_reset(e, p, m, nullptr);                  // adversarial.py:272
       e.elapsed = 0;                                // time_limit.py:43-45
       env_set_encoding(e, p, m, a.enc + (size_t)row * S * S * 3);
+    } else if (OP == OP_FIXED_LEVEL) {
+      env_load_fixed_level(e, p, m, a.enc + (size_t)row * S * S * 3);
+      e.elapsed = 0;                                // TimeLimit.reset
+      e.ep_ret = 0.f; e.ep_len = 0;                 // VecMonitor.reset (vec_monitor.py:36-40)
     } else if (OP == OP_REPLAY) {
       env_reset(e, p, m, nullptr);
       e.elapsed = 0;
@@ -606,6 +610,13 @@ int dcd_mg_reset_to_encoding(DcdMg* h, const uint8_t* enc, const int32_t* idx, i
   if (n < 0 || (!idx && n != h->p.B)) return dcd::fail("dcd_mg_reset_to_encoding: n=%d must equal num_envs=%d when idx is NULL", n, h->p.B);
   LevelArgs a = base_args(h); a.enc = enc; a.idx = idx; a.n_rows = n; if (out) a.stu = *out;
   return launch_level<OP_SET_ENCODING>(h, a, stream);
+}
+int dcd_mg_reset_to_fixed_level(DcdMg* h, const uint8_t* enc, const int32_t* idx, int32_t n, const DcdStudentObs* out, void* stream) {
+  CHECK_H(h);
+  if (!enc) return dcd::fail("dcd_mg_reset_to_fixed_level: null enc");
+  if (n < 0 || (!idx && n != h->p.B)) return dcd::fail("dcd_mg_reset_to_fixed_level: n=%d must equal num_envs=%d when idx is NULL", n, h->p.B);
+  LevelArgs a = base_args(h); a.enc = enc; a.idx = idx; a.n_rows = n; if (out) a.stu = *out;
+  return launch_level<OP_FIXED_LEVEL>(h, a, stream);
 }
 int dcd_mg_reset_to_actions(DcdMg* h, const int64_t* actions, const int32_t* lens, int32_t max_len, const int32_t* idx, int32_t n,
                             const DcdStudentObs* out, void* stream) {

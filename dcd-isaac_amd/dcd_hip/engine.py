@@ -170,6 +170,15 @@ class MultiGridEngine:
             ptr(idx, torch.int32, n, "idx"), C.c_int32(n), C.byref(st), stream_ptr()))
         return out
 
+    def reset_to_fixed_level(self, enc, idx=None, out=None):
+        n = enc.shape[0]
+        out = self.student_buffers(n) if out is None else out
+        st = self._student_struct(out, n)
+        check(lib().dcd_mg_reset_to_fixed_level(
+            self._h, ptr(enc, torch.uint8, n * self.S * self.S * 3, "enc"),
+            ptr(idx, torch.int32, n, "idx"), C.c_int32(n), C.byref(st), stream_ptr()))
+        return out
+
     def reset_to_actions(self, actions, lens, idx=None, out=None):
         n, max_len = actions.shape
         out = self.student_buffers(n) if out is None else out

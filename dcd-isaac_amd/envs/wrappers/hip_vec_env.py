@@ -44,13 +44,21 @@ class HipAdversarialVecEnv:
         p = self.proto
         V, S = p.agent_view_size, p.size
         self.action_space = p.action_space
-        self.adversary_action_space = p.adversary_action_space
         # spaces as seen through VecPreprocessImageWrapper (channels first; obs_wrappers.py:117-146)
         self.observation_space = {"image": spaces.Box(0, 255, (3, V, V), "uint8"),
                                   "direction": p.observation_space["direction"]}
-        self.adversary_observation_space = {"image": spaces.Box(0, 255, (3, S, S), "uint8"),
-                                            "time_step": p.adversary_observation_space["time_step"],
-                                            "random_z": p.adversary_observation_space["random_z"]}
+        self.is_fixed_level = bool(getattr(p, "is_fixed_level", False))
+        if self.is_fixed_level:
+            # evaluation mazes (envs/multigrid/maze.py): one description per env (corridor goals differ per env)
+            descs = [self.proto] + [fn() for fn in env_fns[1:]]
+            self._fixed_levels = torch.from_numpy(np.stack([d.level_encoding() for d in descs])).to(self.device)
+            self.adversary_action_space = None
+            self.adversary_observation_space = None
+        else:
+            self.adversary_action_space = p.adversary_action_space
+            self.adversary_observation_space = {"image": spaces.Box(0, 255, (3, S, S), "uint8"),
+                                                "time_step": p.adversary_observation_space["time_step"],
+                                                "random_z": p.adversary_observation_space["random_z"]}
         self.action_dim = 1
         self.adv_action_dim = 1 if adversary else 0
         self.processed_action_dim = 1
@@ -104,8 +112,19 @@ class HipAdversarialVecEnv:
 
     # ------------------------------------------------------------------ reference-compatible level
     def reset(self):
+        """Adversarial families: AdversarialEnv.reset (teacher obs).  Fixed-level families (eval mazes):
+        MultiGridEnv.reset — reload the level, student obs (eval.py:266)."""
         self._assert_not_closed()
+        if self.is_fixed_level:
+            out = self.engine.reset_to_fixed_level(self._fixed_levels, None, self._student_out())
+            self.raise_errors()
+            return self._student_dict(out)
         return self._adv_dict(self.engine.reset(self.engine.adv_buffers(u8=False)))
+
+    def step(self, actions):
+        """VecEnv.step of the evaluation path (worker `step`, parallel_wrappers.py:20-25: env.reset() on done).
+        For fixed levels reset() restores the same grid, which is what the fused auto-reset does."""
+        return self.step_env(actions, reset_random=False)
 
     def reset_agent(self):
         self._assert_not_closed()

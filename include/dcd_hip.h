@@ -166,6 +166,12 @@ int dcd_mg_reset_random(DcdMg* h, const DcdStudentObs* out, void* stream);
  * enc: uint8[n,S,S,3]; idx: int32[n] env indices or NULL (n == B, identity). */
 int dcd_mg_reset_to_encoding(DcdMg* h, const uint8_t* enc, const int32_t* idx, int32_t n,
                              const DcdStudentObs* out, void* stream);
+/* MultiGridEnv.reset() of a FIXED level family — the zero-shot evaluation mazes (envs/multigrid/maze.py:76-94
+ * as _gen_grid, multigrid.py:470-502; eval.py:250-329 drives them): the grid becomes the given encoding, the
+ * agent starts on its cell facing the ENCODED direction (no random draw), episode / TimeLimit / VecMonitor
+ * counters are zeroed.  Same argument conventions as dcd_mg_reset_to_encoding. */
+int dcd_mg_reset_to_fixed_level(DcdMg* h, const uint8_t* enc, const int32_t* idx, int32_t n,
+                                const DcdStudentObs* out, void* stream);
 /* reset_to_level with an action string (adversarial.py:271-288): actions
  * int64[n,max_len] (row-major), lens int32[n]; replays reset() + step_adversary
  * per action (+ reset_agent when the design episode ends) in ONE launch. */

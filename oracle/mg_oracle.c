@@ -402,6 +402,24 @@ static void env_reset_to_encoding(Env* e, const uint8_t* enc /* [S][S][3] */) {
   env_reset_agent(e);
 }
 
+/* ---- MultiGridEnv.reset of a fixed level (multigrid.py:470-502; maze.py:76-94 as _gen_grid) */
+static void env_load_fixed_level(Env* e, const uint8_t* enc) {
+  e->step_count = 0; e->adversary_step_count = 0;
+  reset_agent_status(e);
+  e->has_start = 0; e->has_goal = 0;
+  reset_metrics(e);
+  for (int i = 0; i < e->H; ++i) for (int j = 0; j < e->W; ++j) {
+    const uint8_t* c = enc + (i * e->W + j) * 3;
+    Obj v;
+    if (decode_obj(c[0], c[1], c[2], &v) != 0) { e->err |= DCD_ERR_BAD_ENCODING; v = OBJ_NONE; }
+    if (v.present && v.type == DCD_OBJ_AGENT) { e->has_start = 1; e->sx = i; e->sy = j; e->sdir = v.state; }
+    else if (v.present && v.type == DCD_OBJ_GOAL) { e->has_goal = 1; e->gx = i; e->gy = j; }
+    grid_set(e, i, j, v);
+  }
+  compute_metrics(e);
+  env_reset_agent(e);
+}
+
 /* ---- reset_random (adversarial.py:541-581) */
 static void env_reset_random(Env* e) {
   if (e->fixed_environment) e->ctr = 0;                                   /* self.seed(seed_value) */
@@ -679,6 +697,16 @@ void orc_mg_reset_to_encoding(OrcMg* h, const uint8_t* enc, const int32_t* idx, 
   for (int r = 0; r < n; ++r) {
     Env* e = &h->envs[idx ? idx[r] : r];
     env_reset_to_encoding(e, enc + (size_t)r * S * S * 3);
+    emit_student_obs(e, r, out);
+  }
+}
+void orc_mg_reset_to_fixed_level(OrcMg* h, const uint8_t* enc, const int32_t* idx, int32_t n,
+                                 const DcdStudentObs* out) {
+  int S = h->cfg.size;
+  for (int r = 0; r < n; ++r) {
+    Env* e = &h->envs[idx ? idx[r] : r];
+    env_load_fixed_level(e, enc + (size_t)r * S * S * 3);
+    e->elapsed = 0; e->epret = 0.f; e->eplen = 0;
     emit_student_obs(e, r, out);
   }
 }

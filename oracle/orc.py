@@ -165,6 +165,14 @@ class OracleMg:
         self._fn("reset_to_encoding")(self.h, _p(enc), _p(idx_a), C.c_int32(n), C.byref(st))
         return bufs
 
+    def reset_to_fixed_level(self, enc, idx=None):
+        enc = np.ascontiguousarray(enc, np.uint8)
+        n = enc.shape[0]
+        idx_a = None if idx is None else np.ascontiguousarray(idx, np.int32)
+        bufs, st = self._student(n)
+        self._fn("reset_to_fixed_level")(self.h, _p(enc), _p(idx_a), C.c_int32(n), C.byref(st))
+        return bufs
+
     def reset_to_actions(self, actions, lens, idx=None):
         actions = np.ascontiguousarray(actions, np.int64)
         lens = np.ascontiguousarray(lens, np.int32)

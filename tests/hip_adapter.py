@@ -49,6 +49,10 @@ class HipMg:
         i = None if idx is None else self._t(idx, torch.int32)
         return _np(self.eng.reset_to_encoding(self._t(enc, torch.uint8), i))
 
+    def reset_to_fixed_level(self, enc, idx=None):
+        i = None if idx is None else self._t(idx, torch.int32)
+        return _np(self.eng.reset_to_fixed_level(self._t(enc, torch.uint8), i))
+
     def reset_to_actions(self, actions, lens, idx=None):
         i = None if idx is None else self._t(idx, torch.int32)
         return _np(self.eng.reset_to_actions(self._t(actions, torch.int64), self._t(lens, torch.int32), i))

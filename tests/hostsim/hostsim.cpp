@@ -142,6 +142,16 @@ void sim_mg_reset_to_encoding(SimMg* h, const uint8_t* enc, const int32_t* idx, 
     e.store_dyn(); emit_student_row(h, e, r, out, nullptr); note(h, i, e.err);
   }
 }
+void sim_mg_reset_to_fixed_level(SimMg* h, const uint8_t* enc, const int32_t* idx, int32_t n, const DcdStudentObs* out) {
+  const int S = h->p.S;
+  for (int r = 0; r < n; ++r) {
+    const int i = idx ? idx[r] : r;
+    ENV(i);
+    env_load_fixed_level(e, h->p, m, enc + (size_t)r * S * S * 3);
+    e.elapsed = 0; e.ep_ret = 0.f; e.ep_len = 0;
+    e.store_dyn(); emit_student_row(h, e, r, out, nullptr); note(h, i, e.err);
+  }
+}
 void sim_mg_reset_to_actions(SimMg* h, const int64_t* actions, const int32_t* lens, int32_t max_len, const int32_t* idx, int32_t n,
                              const DcdStudentObs* out) {
   for (int r = 0; r < n; ++r) {

@@ -84,7 +84,7 @@ def drive(x, y, rng, n_calls=60, steps_per_call=40, exotic=False, action_fn=None
     assert_same(x.reset_agent(), y.reset_agent(), "reset_agent")
     for call in range(n_calls):
         kind = rng.choice(["steps", "steps", "steps", "teacher", "random", "encoding", "encoding_idx", "mutate",
-                           "replay", "steps_rr", "steps_last"])
+                           "replay", "steps_rr", "steps_last", "fixed_level"])
         what = f"call{call}:{kind}"
         if kind == "teacher":
             teacher_build()
@@ -99,6 +99,9 @@ def drive(x, y, rng, n_calls=60, steps_per_call=40, exotic=False, action_fn=None
             idx = rng.permutation(B)[:n]
             enc = random_encodings(rng, n, S, exotic=exotic)
             assert_same(x.reset_to_encoding(enc, idx), y.reset_to_encoding(enc, idx), what)
+        elif kind == "fixed_level":
+            enc = random_encodings(rng, B, S, exotic=exotic)
+            assert_same(x.reset_to_fixed_level(enc), y.reset_to_fixed_level(enc), what)
         elif kind == "mutate":
             ne = int(rng.integers(1, 8))
             assert_same(x.mutate_level(ne), y.mutate_level(ne), what)

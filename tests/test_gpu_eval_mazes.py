@@ -1,0 +1,58 @@
+"""-m gpu: the fixed evaluation mazes on the same step kernel — engine vs oracle on the real maze
+encodings, maze invariants, and the Evaluator end to end."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import orc
+from tests import mg_diff
+
+pytestmark = pytest.mark.gpu
+NAMES = ["MultiGrid-Maze-v0", "MultiGrid-Maze2-v0", "MultiGrid-Maze3-v0", "MultiGrid-SmallCorridor-v0", "MultiGrid-Labyrinth-v0",
+         "MultiGrid-Labyrinth2-v0", "MultiGrid-SixteenRooms-v0", "MultiGrid-SixteenRoomsFewerDoors-v0",
+         "MultiGrid-NineRooms-v0", "MultiGrid-NineRoomsFewerDoors-v0", "MultiGrid-MiniMaze-v0", "MultiGrid-MediumMaze-v0"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_maze_rollout_matches_oracle(name):
+    from envs.registration import make
+    from tests.hip_adapter import HipMg
+    d = make(name)
+    B = 40
+    cfg = dict(num_envs=B, **d.engine_config())
+    x, y = orc.OracleMg(**cfg), HipMg(**cfg)
+    enc = np.stack([make(name).level_encoding() for _ in range(B)])
+    ox, oy = x.reset_to_fixed_level(enc), y.reset_to_fixed_level(enc)
+    mg_diff.assert_same(ox, oy, "reset")
+    st = x.get_state()
+    assert (st[:, 2] == 0).all() and (st[:, 0] == d.start_pos[0]).all() and (st[:, 1] == d.start_pos[1]).all()
+    met = x.get_metrics()
+    assert (met["passable"] == 1).all()                     # every benchmark maze is solvable
+    rng = np.random.default_rng(0)
+    tx = ty = None
+    for t in range(2 * d.max_steps // 3):
+        a = rng.choice(7, size=B, p=[0.2, 0.2, 0.5, 0.025, 0.025, 0.025, 0.025])
+        ox, oy = x.step(a, 0, tx), y.step(a, 0, ty)
+        tx, ty = ox["term_obs"], oy["term_obs"]
+        mg_diff.assert_same(ox, oy, f"step {t}")
+    mg_diff.compare_state(x, y, "end")
+    assert np.array_equal(x.get_encodings()[..., 0] == 2, enc[..., 0] == 2)      # walls never change
+
+
+def test_evaluator_interface():
+    sys_path_ok = __import__("eval")
+    from arguments import parser
+    from util import create_parallel_env, make_agent
+    args = parser.parse_args([])
+    args.num_processes = 32
+    venv, _ = create_parallel_env(args, device="cuda:0")
+    agent = make_agent("agent", venv, args, "cuda:0")
+    names = ["MultiGrid-SixteenRooms-v0", "MultiGrid-MiniMaze-v0"]
+    ev = sys_path_ok.Evaluator(names, num_processes=32, num_episodes=40, device="cuda:0")
+    assert ev.get_stats_keys() == [f"{k}:{n}" for n in names for k in ("solved_rate", "test_returns")]
+    stats = ev.evaluate(agent)
+    for n in names:
+        assert 0.0 <= stats[f"solved_rate:{n}"] <= 1.0 and 0.0 <= stats[f"test_returns:{n}"] <= 1.0
+    raw = ev.evaluate(agent, accumulator=None)
+    assert all(len(raw[f"test_returns:{n}"]) == 40 for n in names)
+    ev.close(); venv.close()
