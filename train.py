@@ -6,9 +6,10 @@ on the MI355X engine.  One process per GPU (launch with torch.distributed.run fo
       --num_processes 4096 --num_steps 256 --handle_timelimits true --recurrent_adversary_env true \
       --num_env_steps 100000000 --log_interval 1
 
-Logging/checkpoint file formats (FileWriter, screenshots, Evaluator on the fixed mazes) are rows of
-SURVEY §8f ("next") and are not built this round: stats go to stdout as JSON lines, checkpoints use
-the reference's state_dict layout through util.safe_checkpoint.
+Logs go to <log_dir>/<xpid>/{logs.csv, fields.csv, meta.json} in the reference's layout (util/filewriter.py) and
+to stdout as JSON lines; checkpoints use the reference's `runner_state_dict` layout through util.safe_checkpoint;
+every --test_interval updates the student is evaluated zero-shot on --test_env_names (eval.Evaluator, the
+15x15 mazes).  Level screenshots (train.py:204-232 of the reference) are UI and not built.
 """
 import json
 import os
@@ -25,6 +26,7 @@ from arguments import parser  # noqa: E402
 from envs.runners import AdversarialRunner  # noqa: E402
 from util import create_parallel_env, make_agent, make_plr_args, safe_checkpoint, seed  # noqa: E402
 from util import distributed as D  # noqa: E402
+from util.filewriter import FileWriter  # noqa: E402
 
 
 def main():
@@ -57,9 +59,23 @@ def main():
                                device=device)
     num_updates = int(args.num_env_steps) // args.num_steps // (args.num_processes * world)
     ckpt = os.path.expandvars(os.path.expanduser(os.path.join(args.log_dir, args.xpid, "model.tar")))
-    last, t0 = 0, timeit.default_timer()
-    for j in range(num_updates):
+    writer = FileWriter(xpid=args.xpid, xp_args=vars(args), rootdir=args.log_dir) if rank == 0 else None
+    evaluator = None
+    if rank == 0 and args.test_env_names and args.test_interval > 0:
+        from eval import Evaluator
+        names = [n for n in args.test_env_names.split(",") if n]
+        try:
+            evaluator = Evaluator(names, num_processes=args.test_num_processes, num_episodes=args.test_num_episodes, device=device)
+        except NotImplementedError as e:                  # e.g. a 21x21 maze
+            print(f"evaluation disabled: {e}", flush=True)
+    if args.checkpoint and os.path.exists(ckpt):          # preemption resume (train.py:129-134)
+        runner.load_state_dict(torch.load(ckpt, map_location=device, weights_only=False)["runner_state_dict"])
+    last, t0 = runner.num_updates, timeit.default_timer()
+    for j in range(runner.num_updates, num_updates):
         stats = runner.run()
+        test_stats = {}
+        if evaluator is not None and (j % args.test_interval == 0 or j == num_updates - 1):
+            test_stats = evaluator.evaluate(runner.agents["agent"])
         if rank == 0 and j % args.log_interval == 0:
             torch.cuda.synchronize()
             now = timeit.default_timer()
@@ -68,11 +84,17 @@ def main():
             last, t0 = j + 1, now
             row = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else None)
                    for k, v in stats.items() if not hasattr(v, "__len__")}
-            row.update(sps=sps, update=j)
-            print(json.dumps(row), flush=True)
+            row.update(test_stats)
+            row.update(sps=sps)
+            writer.log(dict(row))
+            print(json.dumps(dict(row, update=j)), flush=True)
         if rank == 0 and args.checkpoint and j > 0 and j % args.checkpoint_interval == 0:
             os.makedirs(os.path.dirname(ckpt), exist_ok=True)
             safe_checkpoint({"runner_state_dict": runner.state_dict()}, ckpt, index=j, archive_interval=args.archive_interval)
+    if writer is not None:
+        writer.close()
+    if evaluator is not None:
+        evaluator.close()
     venv.close()
 
 
