@@ -37,6 +37,8 @@
 // On the device an env record is ALWAYS in LDS while a lane works on it; typing the pointers as
 // address_space(3) makes every access a ds_read/ds_write (generic "flat" accesses also count on
 // vmcnt and would wait for outstanding global stores).  Host builds (tests/hostsim) use plain pointers.
+// rare-path hints: the hot step falls through; resets, respawns and error paths are laid out cold
+#define DCD_RARE(x) __builtin_expect(!!(x), 0)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DCD_REC __attribute__((address_space(3)))
 #else
@@ -138,11 +140,12 @@ struct Env {
   DCD_HDM DCD_REC uint8_t& cell(int x, int y) { return r[y * ROW + x]; }
   DCD_HDM DCD_REC uint8_t& sb(int k) { return r[k * ROW + 15]; }
   DCD_HDM void set_cell(int x, int y, uint8_t c) {
-    r[y * ROW + x] = c;
-    if (!full_dirty) {
-      const int o = y * ROW + x;
-      if (nd == 0) { doff0 = o; nd = 1; } else if (nd == 1) { doff1 = o; nd = 2; } else full_dirty = true;
-    }
+    const int o = y * ROW + x;
+    r[o] = c;
+    doff1 = (nd == 1) ? o : doff1;            // branch-free: first two writes are remembered, a third
+    doff0 = (nd == 0) ? o : doff0;            // marks the whole record dirty
+    full_dirty = full_dirty || (nd >= 2);
+    nd += 1;
   }
   DCD_HDM bool has_pos() const { return ax != NOPOS; }
   DCD_HDM void pack_dyn(uint32_t w[4]) const {
@@ -497,42 +500,40 @@ DCD_HD double step_one_agent(Env& e, const Params& p, int action, int step_count
   const int d = e.adir;
   const int fx = e.ax + ((d == 0) - (d == 2)), fy = e.ay + ((d == 1) - (d == 3));   // DIR_TO_VEC
   const bool ok = fx >= 0 && fx < p.S && fy >= 0 && fy < p.S;
-  if (!ok) e.err |= DCD_ERR_OUT_OF_GRID;
+  if (DCD_RARE(!ok)) e.err |= DCD_ERR_OUT_OF_GRID;
   const uint8_t fwd = ok ? e.cell(fx, fy) : C_WALL_GREY;
   double reward = 0.0;
-  switch (action) {
-    case DCD_ACT_LEFT: e.adir = (d + 3) & 3; e.set_cell(e.ax, e.ay, (uint8_t)(C_AGENT0 + e.adir)); break;
-    case DCD_ACT_RIGHT: e.adir = (d + 1) & 3; e.set_cell(e.ax, e.ay, (uint8_t)(C_AGENT0 + e.adir)); break;
-    case DCD_ACT_FORWARD:
-      if (!ok) break;
-      if (fwd == C_GOAL) {
-        agent_is_done(e, p, need_respawn_pos);
-        reward = 1.0 - 0.9 * ((double)step_count / (double)p.max_steps);   // MiniGridEnv._reward
-      } else if (fwd == C_LAVA) {
-        agent_is_done(e, p, need_respawn_pos);
-      } else if (fwd == C_NONE || can_overlap(fwd)) {                       // move_agent :840-853
-        e.set_cell(e.ax, e.ay, C_NONE);
-        e.ax = fx; e.ay = fy;
-        e.set_cell(fx, fy, (uint8_t)(C_AGENT0 + d));
-      }
-      break;
-    case DCD_ACT_PICKUP:
-      if (ok && can_pickup(fwd) && e.carrying == C_NONE) { e.carrying = fwd; e.set_cell(fx, fy, C_NONE); }
-      break;
-    case DCD_ACT_DROP:
-      if (ok && fwd == C_NONE && e.carrying != C_NONE) { e.set_cell(fx, fy, (uint8_t)e.carrying); e.carrying = C_NONE; }
-      break;
-    case DCD_ACT_TOGGLE:
-      if (ok && is_door(fwd)) {                                             // Door.toggle multigrid.py:113-123
-        const int dd = fwd - C_DOOR0, col = dd / 3, st = dd % 3;
-        if (st == 2) { if (e.carrying == C_KEY0 + col) e.set_cell(fx, fy, C_DOOR0 + col * 3); }
-        else e.set_cell(fx, fy, C_DOOR0 + col * 3 + (st == 0 ? 1 : 0));
-      } else if (ok && fwd >= C_BOX0 && fwd < C_GOAL) {
-        e.set_cell(fx, fy, C_NONE);                                          // Box.toggle: contents (None)
-      }
-      break;
-    case DCD_ACT_DONE: break;
-    default: e.err |= DCD_ERR_BAD_ACTION; break;
+  // Three divergence classes instead of seven: turns, forward, and "everything else", whose object
+  // interactions (pickup / drop / toggle) only do something next to a key/ball/box/door or while carrying.
+  if (action <= DCD_ACT_RIGHT) {                                            // rotate_agent (:876-885)
+    e.adir = (d + (action == DCD_ACT_LEFT ? 3 : 1)) & 3;
+    e.set_cell(e.ax, e.ay, (uint8_t)(C_AGENT0 + e.adir));
+  } else if (action == DCD_ACT_FORWARD) {
+    if (DCD_RARE(!ok)) {
+    } else if (DCD_RARE(fwd == C_GOAL)) {
+      agent_is_done(e, p, need_respawn_pos);
+      reward = 1.0 - 0.9 * ((double)step_count / (double)p.max_steps);     // MiniGridEnv._reward
+    } else if (DCD_RARE(fwd == C_LAVA)) {
+      agent_is_done(e, p, need_respawn_pos);
+    } else if (fwd == C_NONE || can_overlap(fwd)) {                         // move_agent :840-853
+      e.set_cell(e.ax, e.ay, C_NONE);
+      e.ax = fx; e.ay = fy;
+      e.set_cell(fx, fy, (uint8_t)(C_AGENT0 + d));
+    }
+  } else if (DCD_RARE(action > DCD_ACT_DONE)) {
+    e.err |= DCD_ERR_BAD_ACTION;
+  } else if (DCD_RARE(ok && (e.carrying != C_NONE || fwd >= C_KEY0) && action != DCD_ACT_DONE)) {
+    if (action == DCD_ACT_PICKUP) {                                          // :905-914
+      if (can_pickup(fwd) && e.carrying == C_NONE) { e.carrying = fwd; e.set_cell(fx, fy, C_NONE); }
+    } else if (action == DCD_ACT_DROP) {                                     // :917-924
+      if (fwd == C_NONE && e.carrying != C_NONE) { e.set_cell(fx, fy, (uint8_t)e.carrying); e.carrying = C_NONE; }
+    } else if (is_door(fwd)) {                                               // Door.toggle multigrid.py:113-123
+      const int dd = fwd - C_DOOR0, col = dd / 3, st = dd % 3;
+      if (st == 2) { if (e.carrying == C_KEY0 + col) e.set_cell(fx, fy, (uint8_t)(C_DOOR0 + col * 3)); }
+      else e.set_cell(fx, fy, (uint8_t)(C_DOOR0 + col * 3 + (st == 0 ? 1 : 0)));
+    } else if (fwd >= C_BOX0 && fwd < C_GOAL) {
+      e.set_cell(fx, fy, C_NONE);                                            // Box.toggle: contents (None)
+    }
   }
   return reward;
 }
@@ -572,18 +573,18 @@ DCD_HD StepResult env_step(Env& e, const Params& p, Metrics& m, bool& metrics_di
   const bool will_term = p.max_episode_steps > 0 && e.elapsed + 1 >= p.max_episode_steps;
   const double reward = step_one_agent(e, p, action, step_count, will_term);
   bool done = e.done >= 1;                                               // competitive, n_agents == 1
-  if (step_count >= p.max_steps) done = true;                             // :972-973
+  if (DCD_RARE(step_count >= p.max_steps)) done = true;                   // :972-973
   uint8_t info = 0; bool have_term = false;
   if (p.max_episode_steps > 0) {                                           // time_limit.py:24-33
     const int el = e.elapsed + 1;
     e.elapsed = el;
-    if (el >= p.max_episode_steps) {
+    if (DCD_RARE(el >= p.max_episode_steps)) {
       info |= DCD_INFO_TRUNC_KEY; if (!done) info |= DCD_INFO_TRUNCATED;
       have_term = true; done = true;
     }
   }
-  if (have_term) { render_view(e, p, term); term[p.V * p.V * 3] = (uint8_t)e.adir; }
-  if (done) {                                                              // parallel_wrappers.py:27-37
+  if (DCD_RARE(have_term)) { render_view(e, p, term); term[p.V * p.V * 3] = (uint8_t)e.adir; }
+  if (DCD_RARE(done)) {                                                    // parallel_wrappers.py:27-37
     if (flags & DCD_STEP_RESET_RANDOM) { env_reset_random(e, p, m); metrics_dirty = true; }
     reset_agent(e);
     e.elapsed = 0;                                                         // time_limit.py:39-49
@@ -592,9 +593,9 @@ DCD_HD StepResult env_step(Env& e, const Params& p, Metrics& m, bool& metrics_di
   float epr = (float)((double)e.ep_ret + reward);
   int epl = e.ep_len + 1;
   r.ep_ret = 0.f; r.ep_len = 0;
-  if (done) { info |= DCD_INFO_EPISODE; r.ep_ret = epr; r.ep_len = epl; epr = 0.f; epl = 0; }
+  if (DCD_RARE(done)) { info |= DCD_INFO_EPISODE; r.ep_ret = epr; r.ep_len = epl; epr = 0.f; epl = 0; }
   e.ep_ret = epr; e.ep_len = epl;
-  if (flags & DCD_STEP_LAST) {                                             // adversarial_runner.py:521-530
+  if (DCD_RARE(flags & DCD_STEP_LAST)) {                                   // adversarial_runner.py:521-530
     if (!done) info |= DCD_INFO_CLIFFHANGER | DCD_INFO_TRUNC_KEY | DCD_INFO_TRUNCATED;
     done = true;
   }

@@ -36,20 +36,19 @@ __device__ __forceinline__ int obs_pitch(int V) { return (V * V * 3 + 1 + 3) & ~
 typedef DCD_REC uint8_t lds_u8;      // address_space(3) in the device pass, plain in the host pass
 __device__ __forceinline__ lds_u8* as_lds(uint8_t* p) { return (lds_u8*)p; }
 
-// k/10.0 evaluated in fp64 and rounded once to fp32 (VecPreprocessImageWrapper._preprocess,
-// obs_wrappers.py:90-91,96) for every byte value enc3 can produce (type<=10, colour<=5, state<=3).
-__constant__ float kDiv10[16] = {(float)(0 / 10.0), (float)(1 / 10.0), (float)(2 / 10.0), (float)(3 / 10.0),
-                                 (float)(4 / 10.0), (float)(5 / 10.0), (float)(6 / 10.0), (float)(7 / 10.0),
-                                 (float)(8 / 10.0), (float)(9 / 10.0), (float)(10 / 10.0), (float)(11 / 10.0),
-                                 (float)(12 / 10.0), (float)(13 / 10.0), (float)(14 / 10.0), (float)(15 / 10.0)};
 // LUTs shared by the emission code, indexed by packed cell code: the 3 encoding bytes and their /10 floats
 struct Luts { uint32_t enc[64]; float f[3][64]; float div10[16]; };
+// float(k)/10.0f in IEEE fp32 division equals (float)((double)k/10.0) bit for bit for every byte value
+// (checked for k = 0..255; `float(k)*0.1f` does NOT, first mismatch k = 9) — computed in
+// registers so that building the LUTs needs no memory round trip.  kDiv10 documents the fp64 definition and is
+// what the parity tests compare against through the oracle.
+__device__ __forceinline__ float div10f(uint32_t k) { return __fdiv_rn((float)k, 10.0f); }
 __device__ __forceinline__ void init_luts(Luts& l, int tid) {
   if (tid < 64) {
     const uint32_t t = tid < C_END ? enc3((uint8_t)tid) : 0u;
     l.enc[tid] = t;
-    l.f[0][tid] = kDiv10[t & 15]; l.f[1][tid] = kDiv10[(t >> 8) & 15]; l.f[2][tid] = kDiv10[(t >> 16) & 15];
-    if (tid < 16) l.div10[tid] = kDiv10[tid];
+    l.f[0][tid] = div10f(t & 15); l.f[1][tid] = div10f((t >> 8) & 15); l.f[2][tid] = div10f((t >> 16) & 15);
+    if (tid < 16) l.div10[tid] = div10f((uint32_t)tid);
   }
 }
 

@@ -1,0 +1,95 @@
+"""CPU property tests (hypothesis): size-independent invariants of the env path and the scans, in the spirit of
+the reference's inline asserts (multigrid.py:485-491,844-853; adversarial.py:253-261; storage.py:400-405)."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+from oracle import orc
+from tests import mg_diff
+from tests.hostsim import sim
+
+
+@settings(max_examples=25, deadline=None)
+@given(seed=st.integers(0, 2 ** 31 - 1), size=st.sampled_from([6, 10, 15]), view=st.sampled_from([3, 5, 7]),
+       n_clutter=st.integers(0, 60), goal_last=st.booleans())
+def test_teacher_then_student_invariants(seed, size, view, n_clutter, goal_last):
+    """Any teacher action sequence yields a level with exactly one goal and one agent inside the walls; walls never
+    exceed n_clutter; a student rollout keeps those invariants, rewards only on done, counters reset on done; the
+    device logic agrees with the oracle throughout."""
+    rng = np.random.default_rng(seed)
+    B = 5
+    cfg = dict(num_envs=B, size=size, agent_view_size=view, n_clutter=n_clutter, choose_goal_last=int(goal_last),
+               max_steps=40, max_episode_steps=40, engine_seed=seed & 0xFFFF)
+    x, y = orc.OracleMg(**cfg), sim.HostSimMg(**cfg)
+    x.reset(); y.reset()
+    interior = (size - 2) ** 2
+    for k in range(n_clutter + 2):
+        loc = rng.integers(0, interior, B)
+        ox, oy = x.step_adversary(loc), y.step_adversary(loc)
+    mg_diff.assert_same(ox, oy, "teacher")
+    assert ox["done"].all()
+    g = x.get_encodings()
+    assert ((g[..., 0] == 8).sum(axis=(1, 2)) == 1).all() and ((g[..., 0] == 10).sum(axis=(1, 2)) == 1).all()
+    border = np.ones((size, size), bool); border[1:-1, 1:-1] = False
+    assert (g[:, border][..., 0] == 2).all()
+    met = x.get_metrics()
+    assert (met["n_clutter_placed"] <= n_clutter).all() and (met["n_clutter_placed"] == (g[:, 1:-1, 1:-1, 0] == 2).sum(axis=(1, 2))).all()
+    assert ((met["shortest_path_length"] == interior + 1) == (met["passable"] == 0)).all()
+    assert (met["shortest_path_length"][met["passable"] == 1] >= met["distance_to_goal"][met["passable"] == 1]).all()
+    mg_diff.assert_same(x.reset_agent(), y.reset_agent(), "reset_agent")
+    tx = ty = None
+    for t in range(90):
+        a = rng.integers(0, 7, B)
+        ox, oy = x.step(a, 0, tx), y.step(a, 0, ty)
+        tx, ty = ox["term_obs"], oy["term_obs"]
+        mg_diff.assert_same(ox, oy, f"step{t}")
+        assert ((ox["reward"] > 0) <= (ox["done"] == 1)).all()
+        assert (ox["obs"]["image_u8"][:, view // 2, view - 1, 0] == 1).all()          # own cell renders empty (not carrying)
+        st_ = x.get_state()
+        assert (st_[ox["done"] == 1, 4] == 0).all()
+        g = x.get_encodings()
+        assert ((g[..., 0] == 10).sum(axis=(1, 2)) == 1).all() and ((g[..., 0] == 8).sum(axis=(1, 2)) == 1).all()
+    mg_diff.compare_state(x, y, "end")
+
+
+@settings(max_examples=30, deadline=None)
+@given(seed=st.integers(0, 2 ** 31 - 1), T=st.integers(1, 70), B=st.integers(1, 9), gamma=st.floats(0.9, 1.0), lam=st.floats(0.0, 1.0))
+def test_gae_reduces_to_known_cases(seed, T, B, gamma, lam):
+    rng = np.random.default_rng(seed)
+    r = rng.standard_normal((T, B)).astype(np.float32)
+    v = rng.standard_normal((T + 1, B)).astype(np.float32)
+    m = (rng.random((T + 1, B)) > 0.2).astype(np.float32)
+    # all masks zero: every step is terminal -> returns == rewards exactly (delta = r - v, gae = delta, R = gae + v)
+    z = np.zeros_like(m)
+    out = orc.gae_returns(r, v, z, gamma, lam)[:-1]
+    np.testing.assert_allclose(out, (r - v[:-1]) + v[:-1], rtol=0, atol=0)
+    # lambda = 0: one-step TD target
+    out0 = orc.gae_returns(r, v, m, gamma, 0.0)[:-1]
+    g32 = np.float32(gamma)
+    np.testing.assert_array_equal(out0, ((r + (g32 * v[1:]) * m[1:]) - v[:-1]) + v[:-1])
+    # discounted returns with gamma = 1 and no terminals: suffix sums + bootstrap (float tolerance)
+    d = orc.discounted_returns(r, v, np.ones_like(m), 1.0)
+    ref = np.cumsum(r[::-1].astype(np.float64), axis=0)[::-1] + v[-1].astype(np.float64)
+    np.testing.assert_allclose(d[:-1], ref, rtol=1e-4, atol=1e-4)
+
+
+@settings(max_examples=30, deadline=None)
+@given(seed=st.integers(0, 2 ** 31 - 1), T=st.integers(1, 60), B=st.integers(1, 8), p_done=st.floats(0.0, 0.6))
+def test_episode_records_partition_the_rollout(seed, T, B, p_done):
+    """Records of one env tile [first segment start, T) without gaps or overlaps, in time order; every full record
+    ends at a done step; a trailing partial exists iff the last step is not a done."""
+    rng = np.random.default_rng(seed)
+    m = (rng.random((T + 1, B)) > p_done).astype(np.float32)
+    z = np.zeros((T + 1, B), np.float32)
+    recs = orc.episode_scores(z, z, z[:T], m, np.ones_like(m), np.arange(T * B, dtype=np.int32).reshape(T, B), None, 7)
+    assert list(recs["actor"]) == sorted(recs["actor"])
+    for b in range(B):
+        rb = recs[recs["actor"] == b]
+        assert len(rb) >= 1 and rb["start_t"][0] == 0
+        ends = rb["start_t"] + rb["num_steps"]
+        assert (rb["start_t"][1:] == ends[:-1]).all() and ends[-1] == T and (rb["num_steps"] > 0).all()
+        for rec, e in zip(rb, ends):
+            if rec["flags"] & 1:
+                assert m[e, b] == 0
+            else:
+                assert e == T and m[T, b] > 0
+        assert (rb["seed"] == rb["start_t"] * B + b).all()                 # seed read at the segment's first step
