@@ -27,7 +27,10 @@ using namespace dcd;
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int NT = 256;            // threads per workgroup: wave 0 runs the per-env logic, all 4 waves stage and emit
+// threads per workgroup: wave 0 runs the per-env logic, ALL waves stage records and emit observations.
+// Small batches (EPB 16/32: latency-bound, one workgroup per CU) use 512 threads so the fused render is one
+// slot per thread; large batches (EPB 64: bandwidth-bound) use 256 to keep more workgroups resident.
+template <int EPB> struct Threads { static constexpr int value = EPB == 64 ? 256 : 512; };
 constexpr int LP = 272;            // LDS pitch of one env record
 constexpr int MAX_OP = 152;        // staged u8 obs per env: V*V*3 + dir, padded (V<=7 -> 148)
 
@@ -53,10 +56,10 @@ __device__ __forceinline__ void init_luts(Luts& l, int tid) {
 }
 
 // ---- workgroup-cooperative record staging: n rows x 16 chunks of 16 B over NT threads ---------
-template <int ROWS>
+template <int ROWS, int NT>
 struct StageBuf { uint4 v[(ROWS * 16 + NT - 1) / NT]; };
-template <int ROWS, class RowToEnv>
-__device__ __forceinline__ void stage_load(StageBuf<ROWS>& sb, const uint8_t* __restrict__ rec, RowToEnv env_of, int n, int tid) {
+template <int ROWS, int NT, class RowToEnv>
+__device__ __forceinline__ void stage_load(StageBuf<ROWS, NT>& sb, const uint8_t* __restrict__ rec, RowToEnv env_of, int n, int tid) {
 #pragma unroll
   for (int i = 0; i < (ROWS * 16 + NT - 1) / NT; ++i) {
     const int q = i * NT + tid, row = q >> 4, c = q & 15;
@@ -64,15 +67,15 @@ __device__ __forceinline__ void stage_load(StageBuf<ROWS>& sb, const uint8_t* __
     if (row < n) sb.v[i] = *reinterpret_cast<const uint4*>(rec + (size_t)env_of(row) * REC_BYTES + c * 16);
   }
 }
-template <int ROWS>
-__device__ __forceinline__ void stage_commit(const StageBuf<ROWS>& sb, uint8_t* lds, int n, int tid) {
+template <int ROWS, int NT>
+__device__ __forceinline__ void stage_commit(const StageBuf<ROWS, NT>& sb, uint8_t* lds, int n, int tid) {
 #pragma unroll
   for (int i = 0; i < (ROWS * 16 + NT - 1) / NT; ++i) {
     const int q = i * NT + tid, row = q >> 4, c = q & 15;
     if (row < n) *reinterpret_cast<uint4*>(lds + row * LP + c * 16) = sb.v[i];
   }
 }
-template <class RowToEnv>
+template <int NT, class RowToEnv>
 __device__ __forceinline__ void stage_out(const uint8_t* lds, uint8_t* __restrict__ rec, RowToEnv env_of, int n, int tid) {
   for (int q = tid; q < n * 16; q += NT) {
     const int row = q >> 4, c = q & 15;
@@ -85,17 +88,21 @@ __device__ __forceinline__ void stage_out(const uint8_t* lds, uint8_t* __restric
 // multigrid.py:1080-1093, packed code from the LDS record, channel values from the code LUTs, stored
 // as fp32 CHW (/10) and/or u8 [vx][vy][c].  Consecutive threads hit consecutive view cells of the same
 // env, so each channel's store is a run of contiguous floats.  Semantics == dcd::render_view.
-template <int V, int ROWS>
+template <int V, int ROWS, int NT>
 __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
                                             int n, int S, int tid) {
-  constexpr int VV = V * V, H = V / 2, ITERS = (ROWS * VV + NT - 1) / NT;
-  if (o.image_u8 || o.image_f32) {
+  // TPE threads per env (power of two >= V*V): env = slot >> log2(TPE), view cell = slot & (TPE-1) — shifts
+  // and masks instead of divisions; all offsets are 32-bit from per-workgroup base pointers.
+  constexpr int VV = V * V, H = V / 2, TPE = VV <= 16 ? 16 : (VV <= 32 ? 32 : 64), ITERS = (ROWS * TPE + NT - 1) / NT;
+  float* __restrict__ f32 = o.image_f32 ? o.image_f32 + out_row0 * (3 * VV) : nullptr;
+  uint8_t* __restrict__ u8 = o.image_u8 ? o.image_u8 + out_row0 * (3 * VV) : nullptr;
+  if (f32 || u8) {
     int code[ITERS];
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {                         // phase 1: all LDS gathers in flight together
-      const int q = i * NT + tid, row = q / VV, ci = q - row * VV, vx = ci / V, vy = ci - vx * V;
+      const int q = i * NT + tid, row = q / TPE, ci = q & (TPE - 1), vx = ci / V, vy = ci - vx * V;
       code[i] = -1;
-      if (q < n * VV) {
+      if (row < n && ci < VV) {
         const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + row * LP + DYN);
         const int ax = dyn & 255, ay = (dyn >> 8) & 255, d = (dyn >> 16) & 255;
         const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
@@ -110,20 +117,19 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
     __builtin_amdgcn_sched_barrier(0);                       // keep the gathers batched ahead of the LUT/store phase
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {                         // phase 2: LUT + stores
-      const int q = i * NT + tid, row = q / VV, ci = q - row * VV;
+      const int q = i * NT + tid, row = q / TPE, ci = q & (TPE - 1);
       if (code[i] < 0) continue;
       const bool none = code[i] == 64;
       const int c = none ? 0 : code[i];
-      const size_t r = out_row0 + row;
-      if (o.image_f32) {
-        float* f = o.image_f32 + r * (3 * VV) + ci;
+      const unsigned off = (unsigned)(row * (3 * VV) + ci);
+      if (f32) {
         const float f0 = lut.f[0][c], f1 = lut.f[1][c], f2 = lut.f[2][c];
-        f[0] = none ? 0.f : f0; f[VV] = none ? 0.f : f1; f[2 * VV] = none ? 0.f : f2;
+        f32[off] = none ? 0.f : f0; f32[off + VV] = none ? 0.f : f1; f32[off + 2 * VV] = none ? 0.f : f2;
       }
-      if (o.image_u8) {
+      if (u8) {
         const uint32_t t = none ? 0u : lut.enc[c];
-        uint8_t* u = o.image_u8 + (r * VV + ci) * 3;
-        u[0] = (uint8_t)t; u[1] = (uint8_t)(t >> 8); u[2] = (uint8_t)(t >> 16);
+        const unsigned uo = (unsigned)(row * (3 * VV) + ci * 3);
+        u8[uo] = (uint8_t)t; u8[uo + 1] = (uint8_t)(t >> 8); u8[uo + 2] = (uint8_t)(t >> 16);
       }
     }
   }
@@ -134,16 +140,17 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
     if (o.dir_f32) o.dir_f32[out_row0 + tid] = (float)d;
   }
 }
-template <int ROWS>
+template <int ROWS, int NT>
 __device__ __forceinline__ void render_emit_v(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
                                               int n, int S, int V, int tid) {
-  if (V == 5) render_emit<5, ROWS>(lds, lut, o, out_row0, n, S, tid);
-  else if (V == 7) render_emit<7, ROWS>(lds, lut, o, out_row0, n, S, tid);
-  else render_emit<3, ROWS>(lds, lut, o, out_row0, n, S, tid);
+  if (V == 5) render_emit<5, ROWS, NT>(lds, lut, o, out_row0, n, S, tid);
+  else if (V == 7) render_emit<7, ROWS, NT>(lds, lut, o, out_row0, n, S, tid);
+  else render_emit<3, ROWS, NT>(lds, lut, o, out_row0, n, S, tid);
 }
 
 // ---- emission of per-lane staged observations (terminal obs: rare) ---------------------------
 // sobs: [n][OP] bytes ([vx][vy][c] then dir); rows with valid[row]==0 are left untouched.
+template <int NT>
 __device__ __forceinline__ void emit_staged(const uint8_t* sobs, const Luts& lut, const DcdStudentObs& o,
                                             size_t out_row0, int n, int V, int tid, const uint8_t* valid) {
   const int VV = V * V, E = VV * 3, OP = obs_pitch(V);
@@ -185,10 +192,21 @@ struct StepArgs {
 // EPB = envs per workgroup.  Threads [0,EPB) of wave 0 run the per-env logic; ALL 256 threads share
 // staging and the fused render/emit.  Small batches use EPB=16 so that B=4096 still spreads over all
 // 256 CUs; large batches use EPB=64 (every lane of the logic wave busy).
+// per-env results handed from the logic lane to the duty waves through LDS
+struct StepRes { float reward, ep_ret; int ep_len; uint32_t flags; uint32_t doff; };   // flags: done | info<<8 | full_dirty<<16 | nd<<20
+
+// Workgroup = NT worker threads + 2 duty waves.  Thread roles:
+//   wave 0, lanes [0,EPB)      per-env logic (one env per lane), result -> LDS
+//   all NT worker threads      record staging before, fused render+emit after the logic
+//   duty wave A (tid NT+lane)  per-env scalar outputs (reward, done, info, episode stats, masks) -> global
+//   duty wave B (tid NT+64+lane) record write-back: 16-byte dynamic state + the <=2 cells changed (or the whole record)
+// so the logic wave's critical path holds no global stores at all.
 template <bool RANDOM, int EPB>
-__global__ void __launch_bounds__(NT) mg_step_kernel(Params p, StepArgs a) {
+__global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel(Params p, StepArgs a) {
+  constexpr int NT = Threads<EPB>::value;
   __shared__ __attribute__((aligned(16))) uint8_t lds[EPB * LP];
   __shared__ __attribute__((aligned(16))) uint8_t sterm[EPB * MAX_OP];
+  __shared__ StepRes res[EPB];
   __shared__ uint8_t term_valid[EPB];
   __shared__ int any_term;
   __shared__ Luts lut;
@@ -197,14 +215,14 @@ __global__ void __launch_bounds__(NT) mg_step_kernel(Params p, StepArgs a) {
   const int OP = obs_pitch(p.V);
   STAMP(0);
   // issue every independent global load up front: records, action, seed (one HBM round trip in all)
-  StageBuf<EPB> sb;
-  stage_load<EPB>(sb, a.rec, [env0](int row) { return env0 + row; }, n, tid);
+  StageBuf<EPB, NT> sb;
+  if (tid < NT) stage_load<EPB, NT>(sb, a.rec, [env0](int row) { return env0 + row; }, n, tid);
   int64_t act0 = 0; uint32_t seed = 0;
   if (tid < n) { seed = a.seed[env]; if (!RANDOM) act0 = a.actions[env]; term_valid[tid] = 0; }
   if (tid == 0) any_term = 0;
   init_luts(lut, tid);
   STAMP(1);
-  stage_commit<EPB>(sb, lds, n, tid);
+  if (tid < NT) stage_commit<EPB, NT>(sb, lds, n, tid);
   __syncthreads();
   STAMP(2);
 
@@ -212,7 +230,7 @@ __global__ void __launch_bounds__(NT) mg_step_kernel(Params p, StepArgs a) {
   if (tid < n) {
     Env e = make_env(as_lds(lds + tid * LP), seed);
     Metrics m = {0, 0, 0, 0}; bool mdirty = false;
-    if (a.flags & DCD_STEP_RESET_RANDOM) m = a.met[env];
+    if (DCD_RARE(a.flags & DCD_STEP_RESET_RANDOM)) m = a.met[env];
     StepResult r;
     const int K = RANDOM ? a.K : 1;
     for (int k = 0; k < K; ++k) {
@@ -226,42 +244,61 @@ __global__ void __launch_bounds__(NT) mg_step_kernel(Params p, StepArgs a) {
       r = env_step(e, p, m, mdirty, act, fl, as_lds(sterm + tid * OP));
       if (RANDOM) episodes += (r.info & DCD_INFO_EPISODE) ? 1 : 0;
     }
-    if (r.have_term) { term_valid[tid] = 1; any_term = 1; }
+    if (DCD_RARE(r.have_term)) { term_valid[tid] = 1; any_term = 1; }
+    e.store_dyn();                                   // LDS copy feeds the render and the write-back wave
+    StepRes sr;
+    sr.reward = r.reward; sr.ep_ret = r.ep_ret; sr.ep_len = r.ep_len;
+    sr.flags = (uint32_t)r.done | ((uint32_t)r.info << 8) | ((uint32_t)(e.full_dirty ? 1 : 0) << 16) | ((uint32_t)min(e.nd, 2) << 20);
+    sr.doff = (uint32_t)e.doff0 | ((uint32_t)e.doff1 << 16);
+    res[tid] = sr;
+    if (DCD_RARE(mdirty)) a.met[env] = m;
+    if (DCD_RARE(e.err)) raise(a.errs, e.err, env);
     STAMP(3);
-    e.store_dyn();                                   // LDS copy feeds the cooperative render below
-    // write-back: dyn always; cells by dirty list or whole record (LDS reads first, then the stores)
-    uint8_t* g = a.rec + (size_t)env * REC_BYTES;
-    uint32_t w[4]; e.pack_dyn(w);
-    if (e.full_dirty) {
-      uint4 rows[15];
-#pragma unroll
-      for (int y = 0; y < 15; ++y) rows[y] = *reinterpret_cast<const uint4*>(lds + tid * LP + y * ROW);
-#pragma unroll
-      for (int y = 0; y < 15; ++y) *reinterpret_cast<uint4*>(g + y * ROW) = rows[y];
-    } else {
-      const uint8_t c0 = lds[tid * LP + e.doff0], c1 = lds[tid * LP + e.doff1];
-      if (e.nd > 0) g[e.doff0] = c0;
-      if (e.nd > 1) g[e.doff1] = c1;
-    }
-    *reinterpret_cast<uint4*>(g + DYN) = make_uint4(w[0], w[1], w[2], w[3]);
-    if (mdirty) a.met[env] = m;
-    raise(a.errs, e.err, env);
-    const DcdStepOut& o = a.out;
-    if (o.reward) o.reward[env] = r.reward;
-    if (o.done) o.done[env] = r.done;
-    if (o.info) o.info[env] = r.info;
-    if (o.ep_ret) o.ep_ret[env] = r.ep_ret;
-    if (o.ep_len) o.ep_len[env] = r.ep_len;
-    if (o.masks) o.masks[env] = r.done ? 0.f : 1.f;                                      // runner :566-573
-    if (o.bad_masks) o.bad_masks[env] = (r.info & DCD_INFO_TRUNC_KEY) ? 0.f : 1.f;
-    if (o.cliffhanger_masks) o.cliffhanger_masks[env] = (r.info & DCD_INFO_CLIFFHANGER) ? 0.f : 1.f;
   }
   __syncthreads();
   STAMP(4);
-  render_emit_v<EPB>(lds, lut, a.out.obs, (size_t)env0, n, p.S, p.V, tid);     // post-auto-reset observation
-  STAMP(5);
-  if (any_term) emit_staged(sterm, lut, a.out.term_obs, (size_t)env0, n, p.V, tid, term_valid);
-  STAMP(6);
+  if (tid < NT) {
+    render_emit_v<EPB, NT>(lds, lut, a.out.obs, (size_t)env0, n, p.S, p.V, tid);     // post-auto-reset observation
+    STAMP(5);
+    if (any_term) emit_staged<NT>(sterm, lut, a.out.term_obs, (size_t)env0, n, p.V, tid, term_valid);
+    STAMP(6);
+  } else if (tid < NT + WAVE) {                      // duty wave A: per-env scalar outputs
+    const int l = tid - NT, ev = env0 + l;
+    if (l < n) {
+      const StepRes sr = res[l];
+      const uint32_t done = sr.flags & 255, info = (sr.flags >> 8) & 255;
+      const DcdStepOut& o = a.out;
+      if (o.reward) o.reward[ev] = sr.reward;
+      if (o.done) o.done[ev] = (uint8_t)done;
+      if (o.info) o.info[ev] = (uint8_t)info;
+      if (o.ep_ret) o.ep_ret[ev] = sr.ep_ret;
+      if (o.ep_len) o.ep_len[ev] = sr.ep_len;
+      if (o.masks) o.masks[ev] = done ? 0.f : 1.f;                                       // runner :566-573
+      if (o.bad_masks) o.bad_masks[ev] = (info & DCD_INFO_TRUNC_KEY) ? 0.f : 1.f;
+      if (o.cliffhanger_masks) o.cliffhanger_masks[ev] = (info & DCD_INFO_CLIFFHANGER) ? 0.f : 1.f;
+    }
+  } else {                                           // duty wave B: record write-back
+    const int l = tid - NT - WAVE, ev = env0 + l;
+    if (l < n) {
+      const StepRes sr = res[l];
+      uint8_t* g = a.rec + (size_t)ev * REC_BYTES;
+      const uint8_t* src = lds + l * LP;
+      if ((sr.flags >> 16) & 1) {
+        uint4 rows[16];
+#pragma unroll
+        for (int y = 0; y < 16; ++y) rows[y] = *reinterpret_cast<const uint4*>(src + y * ROW);
+#pragma unroll
+        for (int y = 0; y < 16; ++y) *reinterpret_cast<uint4*>(g + y * ROW) = rows[y];
+      } else {
+        const int nd = (sr.flags >> 20) & 3, o0 = sr.doff & 0xFFFF, o1 = sr.doff >> 16;
+        const uint4 dyn = *reinterpret_cast<const uint4*>(src + DYN);
+        const uint8_t c0 = src[o0], c1 = src[o1];
+        if (nd > 0) g[o0] = c0;
+        if (nd > 1) g[o1] = c1;
+        *reinterpret_cast<uint4*>(g + DYN) = dyn;
+      }
+    }
+  }
   if (RANDOM && a.n_episodes && tid < WAVE) {
     for (int off = 32; off > 0; off >>= 1) episodes += __shfl_down(episodes, off);
     if (tid == 0 && episodes) atomicAdd(a.n_episodes, episodes);
@@ -286,7 +323,7 @@ struct LevelArgs {
 
 // full-grid observation of the workgroup's n envs: u8 [x][y][c] and/or fp32 CHW /10, contiguous per
 // workgroup (identity rows only).  SS = compile-time grid size (0: runtime p.S).
-template <int SS>
+template <int SS, int NT>
 __device__ __forceinline__ void emit_grid(const uint8_t* lds, const Luts& lut, uint8_t* u8, float* f32, size_t row0, int n,
                                           int S_rt, int tid) {
   const int S = SS ? SS : S_rt, G = S * S * 3, SQ = S * S;
@@ -307,7 +344,8 @@ __device__ __forceinline__ void emit_grid(const uint8_t* lds, const Luts& lut, u
 }
 
 template <int OP, int EPB>
-__global__ void __launch_bounds__(NT) mg_level_kernel(Params p, LevelArgs a) {
+__global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(Params p, LevelArgs a) {
+  constexpr int NT = Threads<EPB>::value;
   __shared__ __attribute__((aligned(16))) uint8_t lds[EPB * LP];
   __shared__ int env_of[EPB];
   __shared__ uint32_t zctr[EPB];                  // per-row rng counter at which this call's random_z starts
@@ -319,9 +357,9 @@ __global__ void __launch_bounds__(NT) mg_level_kernel(Params p, LevelArgs a) {
   init_luts(lut, tid);
   __syncthreads();
   {
-    StageBuf<EPB> sb;
-    stage_load<EPB>(sb, a.rec, [&](int r) { return env_of[r]; }, n, tid);
-    stage_commit<EPB>(sb, lds, n, tid);
+    StageBuf<EPB, NT> sb;
+    stage_load<EPB, NT>(sb, a.rec, [&](int r) { return env_of[r]; }, n, tid);
+    stage_commit<EPB, NT>(sb, lds, n, tid);
   }
   __syncthreads();
 
@@ -373,7 +411,7 @@ __global__ void __launch_bounds__(NT) mg_level_kernel(Params p, LevelArgs a) {
     }
   }
   __syncthreads();
-  if (OP != OP_READ_ENC) stage_out(lds, a.rec, [&](int r) { return env_of[r]; }, n, tid);
+  if (OP != OP_READ_ENC) stage_out<NT>(lds, a.rec, [&](int r) { return env_of[r]; }, n, tid);
   if (ADV_OUT) {
     if (OP != OP_READ_ENC && a.adv.random_z) {
       // generate_random_z (adversarial.py:449-450): (row, q) pairs, one Philox block = 4 floats each
@@ -390,10 +428,10 @@ __global__ void __launch_bounds__(NT) mg_level_kernel(Params p, LevelArgs a) {
     }
     uint8_t* u8 = (OP == OP_READ_ENC) ? a.enc_out : a.adv.image_u8;
     float* f32 = (OP == OP_READ_ENC) ? nullptr : a.adv.image_f32;
-    if (S == 15) emit_grid<15>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
-    else emit_grid<0>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
+    if (S == 15) emit_grid<15, NT>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
+    else emit_grid<0, NT>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
   } else {
-    render_emit_v<EPB>(lds, lut, a.stu, (size_t)row0, n, S, p.V, tid);
+    render_emit_v<EPB, NT>(lds, lut, a.stu, (size_t)row0, n, S, p.V, tid);
   }
 }
 
@@ -501,10 +539,10 @@ static LevelArgs base_args(DcdMg* h) {
 template <int OP> static int launch_level(DcdMg* h, const LevelArgs& a, void* stream) {
   if (a.n_rows <= 0) return 0;
   const int epb = step_epb(a.n_rows);
-  const dim3 grid((a.n_rows + epb - 1) / epb), block(NT);
-  if (epb == 16) hipLaunchKernelGGL((mg_level_kernel<OP, 16>), grid, block, 0, (hipStream_t)stream, h->p, a);
-  else if (epb == 32) hipLaunchKernelGGL((mg_level_kernel<OP, 32>), grid, block, 0, (hipStream_t)stream, h->p, a);
-  else hipLaunchKernelGGL((mg_level_kernel<OP, 64>), grid, block, 0, (hipStream_t)stream, h->p, a);
+  const dim3 grid((a.n_rows + epb - 1) / epb);
+  if (epb == 16) hipLaunchKernelGGL((mg_level_kernel<OP, 16>), grid, dim3(Threads<16>::value), 0, (hipStream_t)stream, h->p, a);
+  else if (epb == 32) hipLaunchKernelGGL((mg_level_kernel<OP, 32>), grid, dim3(Threads<32>::value), 0, (hipStream_t)stream, h->p, a);
+  else hipLaunchKernelGGL((mg_level_kernel<OP, 64>), grid, dim3(Threads<64>::value), 0, (hipStream_t)stream, h->p, a);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -642,10 +680,10 @@ int dcd_mg_step(DcdMg* h, const int64_t* actions, int32_t flags, const DcdStepOu
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) { e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1]; h->ev_used += 2; }
   const int epb = step_epb(h->p.B);
-  const dim3 grid((h->p.B + epb - 1) / epb), block(NT);
-  if (epb == 16) hipExtLaunchKernelGGL((mg_step_kernel<false, 16>), grid, block, 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
-  else if (epb == 32) hipExtLaunchKernelGGL((mg_step_kernel<false, 32>), grid, block, 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
-  else hipExtLaunchKernelGGL((mg_step_kernel<false, 64>), grid, block, 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
+  const dim3 grid((h->p.B + epb - 1) / epb);
+  if (epb == 16) hipExtLaunchKernelGGL((mg_step_kernel<false, 16>), grid, dim3(Threads<16>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
+  else if (epb == 32) hipExtLaunchKernelGGL((mg_step_kernel<false, 32>), grid, dim3(Threads<32>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
+  else hipExtLaunchKernelGGL((mg_step_kernel<false, 64>), grid, dim3(Threads<64>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -691,10 +729,10 @@ int dcd_mg_step_random(DcdMg* h, uint32_t action_seed, uint32_t t0, int32_t K, i
   a.n_episodes = reinterpret_cast<unsigned long long*>(n_episodes);
   if (out) a.out = *out;
   const int epb = step_epb(h->p.B);
-  const dim3 grid((h->p.B + epb - 1) / epb), block(NT);
-  if (epb == 16) hipLaunchKernelGGL((mg_step_kernel<true, 16>), grid, block, 0, (hipStream_t)stream, h->p, a);
-  else if (epb == 32) hipLaunchKernelGGL((mg_step_kernel<true, 32>), grid, block, 0, (hipStream_t)stream, h->p, a);
-  else hipLaunchKernelGGL((mg_step_kernel<true, 64>), grid, block, 0, (hipStream_t)stream, h->p, a);
+  const dim3 grid((h->p.B + epb - 1) / epb);
+  if (epb == 16) hipLaunchKernelGGL((mg_step_kernel<true, 16>), grid, dim3(Threads<16>::value + 2 * WAVE), 0, (hipStream_t)stream, h->p, a);
+  else if (epb == 32) hipLaunchKernelGGL((mg_step_kernel<true, 32>), grid, dim3(Threads<32>::value + 2 * WAVE), 0, (hipStream_t)stream, h->p, a);
+  else hipLaunchKernelGGL((mg_step_kernel<true, 64>), grid, dim3(Threads<64>::value + 2 * WAVE), 0, (hipStream_t)stream, h->p, a);
   HIP_OK(hipGetLastError());
   return 0;
 }
