@@ -26,6 +26,11 @@ class PPO:
         self.log_grad_norm = log_grad_norm
         self.process_group = process_group
         self._flat_grad = None
+        if self.world_size > 1:                                      # ranks seed differently (env streams): start from rank 0's weights
+            import torch.distributed as dist
+            src = dist.get_global_rank(process_group, 0)
+            for t in list(actor_critic.parameters()) + list(actor_critic.buffers()):
+                dist.broadcast(t.data, src=src, group=process_group)
 
     # ---- distributed helpers ----------------------------------------------------------------
     @property

@@ -46,8 +46,16 @@ class RunningMeanStd:
 
 class AdversarialRunner:
     def __init__(self, args, venv, agent, ued_venv=None, adversary_agent=None, adversary_env=None,
-                 flexible_protagonist=False, train=False, plr_args=None, device="cpu"):
+                 flexible_protagonist=False, train=False, plr_args=None, device="cpu", process_group=None):
+        """`process_group` (not in the reference): the env batch is sharded over its ranks, `venv` holds this
+        rank's `args.num_processes` envs; level replay then goes through level_replay.sharded (one sampler on
+        rank 0, replicated level store) and host-side random decisions are taken on rank 0."""
         self.args = args
+        self.process_group = process_group
+        self.world_size = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world_size = dist.get_world_size(process_group)
         self.venv = venv
         self.ued_venv = venv if ued_venv is None else ued_venv
         self.is_discrete_actions = is_discrete_actions(self.venv)
@@ -73,21 +81,27 @@ class AdversarialRunner:
         self.weighted_num_edits = 0
         self.latest_env_stats = defaultdict(float)
         if plr_args:
+            if self.world_size > 1:
+                from level_replay.sharded import ShardedLevelSampler, ShardedLevelStore
+                make_sampler = lambda: ShardedLevelSampler(plr_args, group=process_group)
+                make_store = lambda **kw: ShardedLevelStore(group=process_group, **kw)
+            else:
+                make_sampler = lambda: LevelSampler(**plr_args)
+                make_store = LevelStore
             if self.is_paired:
                 if not args.protagonist_plr and not args.antagonist_plr:
-                    self.level_samplers.update({"agent": LevelSampler(**plr_args),
-                                                "adversary_agent": LevelSampler(**plr_args)})
+                    self.level_samplers.update({"agent": make_sampler(), "adversary_agent": make_sampler()})
                 elif args.protagonist_plr:
-                    self.level_samplers["agent"] = LevelSampler(**plr_args)
+                    self.level_samplers["agent"] = make_sampler()
                 elif args.antagonist_plr:
-                    self.level_samplers["adversary_agent"] = LevelSampler(**plr_args)
+                    self.level_samplers["adversary_agent"] = make_sampler()
             else:
-                self.level_samplers["agent"] = LevelSampler(**plr_args)
+                self.level_samplers["agent"] = make_sampler()
             if self.use_byte_encoding:
                 example = self.ued_venv.get_encodings()[0]
-                self.level_store = LevelStore(data_info={"numpy": True, "dtype": example.dtype, "shape": example.shape})
+                self.level_store = make_store(data_info={"numpy": True, "dtype": example.dtype, "shape": example.shape})
             else:
-                self.level_store = LevelStore()
+                self.level_store = make_store()
             self.current_level_seeds = [-1 for _ in range(args.num_processes)]
             self._default_level_sampler = self.all_level_samplers[0]
             self.use_editor = args.use_editor
@@ -161,6 +175,14 @@ class AdversarialRunner:
                     "level_store", "level_samplers"):
             setattr(self, key, sd.get(key))
         if self.args.use_plr:
+            if self.world_size > 1:                                   # checkpoint written by rank 0: re-attach the group
+                import torch.distributed as dist
+                self.level_store.group = self.process_group
+                for s in self.all_level_samplers:
+                    s.group = self.process_group
+                    s.rank, s.world = dist.get_rank(self.process_group), self.world_size
+                    if s.rank != 0:
+                        s.sampler = None
             self._default_level_sampler = self.all_level_samplers[0]
             if self.use_editor:
                 self.weighted_num_edits = self._get_weighted_num_edits()
@@ -226,8 +248,17 @@ class AdversarialRunner:
     def all_level_samplers(self):
         return [v for v in self.level_samplers.values() if v is not None]
 
+    def _from_rank0(self, value):
+        """Host-side random decisions must agree on every rank: rank 0's draw wins."""
+        if self.world_size == 1:
+            return value
+        import torch.distributed as dist
+        box = [value]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.process_group, 0), group=self.process_group)
+        return box[0]
+
     def _should_edit_level(self):
-        return bool(self.use_editor and np.random.rand() < self.edit_prob)
+        return bool(self._from_rank0(bool(self.use_editor and np.random.rand() < self.edit_prob)))
 
     def _update_plr_with_current_unseen_levels(self, parent_seeds=None):
         levels = self._get_active_levels()
@@ -313,10 +344,10 @@ class AdversarialRunner:
         """PLR replay rollouts: every env that finished an episode gets a new replay level
         (:551-558).  Needs the done mask on the host: one synchronisation per step."""
         finished = (st.ep_info[step] & dcd_hip.INFO_EPISODE).nonzero().flatten()
-        if finished.numel() == 0:
-            return
         idx = finished.cpu().tolist()
-        seeds = [level_sampler.sample_replay_level() for _ in idx]
+        seeds = level_sampler.sample_replay_levels(len(idx))            # a collective when sharded: never skipped
+        if not idx:
+            return
         levels = [self.level_store.get_level(s) for s in seeds]
         kind, a, b = self.venv._levels_to_device(levels)
         idx_dev = finished.to(torch.int32)
@@ -383,7 +414,7 @@ class AdversarialRunner:
                 self._update_plr_with_current_unseen_levels(parent_seeds=fixed_seeds)
                 return
             if level_replay:
-                self.current_level_seeds = [level_sampler.sample_replay_level() for _ in range(B)]
+                self.current_level_seeds = level_sampler.sample_replay_levels(B)
                 levels = [self.level_store.get_level(seed) for seed in self.current_level_seeds]
                 self.ued_venv.reset_to_level_batch(levels)
                 return self.current_level_seeds

@@ -33,7 +33,7 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
-def all_gather_records(recs, device):
+def all_gather_records(recs, device, group=None):
     """recs: numpy structured array (8 x 4-byte fields) of this rank -> list of per-rank arrays on every
     rank.  Variable lengths: counts first, then one padded all_gather."""
     dtype = recs.dtype
@@ -41,14 +41,14 @@ def all_gather_records(recs, device):
         return [recs]
     n = torch.tensor([len(recs)], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(n) for _ in range(world_size())]
-    dist.all_gather(counts, n)
+    dist.all_gather(counts, n, group=group)
     counts = [int(c.item()) for c in counts]
     mx = max(max(counts), 1)
     buf = torch.zeros((mx, 8), dtype=torch.int32, device=device)
     if len(recs):
         buf[:len(recs)] = torch.from_numpy(np.ascontiguousarray(recs).view(np.int32).reshape(-1, 8)).to(device)
     out = [torch.zeros_like(buf) for _ in range(world_size())]
-    dist.all_gather(out, buf)
+    dist.all_gather(out, buf, group=group)
     return [o[:c].cpu().numpy().view(dtype).reshape(c) for o, c in zip(out, counts)]
 
 
@@ -76,3 +76,22 @@ def scatter_rows(t, rows_per_rank):
     dist.broadcast(t, src=0)
     r = rank()
     return t[r * rows_per_rank:(r + 1) * rows_per_rank]
+
+
+SUM_KEYS = ("steps", "total_episodes", "total_seeds")
+
+
+def reduce_stats(stats, sum_keys=SUM_KEYS):
+    """Per-rank `AdversarialRunner.run()` stats -> job-wide stats on every rank: counters are summed, every
+    other numeric entry is averaged over the ranks that report it (None = not reported, as in the reference's
+    plr_* / non-plr_* key pairs); non-numeric entries keep rank 0's value."""
+    if world_size() == 1:
+        return stats
+    parts = [None] * world_size()
+    num = {k: float(v) for k, v in stats.items() if isinstance(v, (int, float, np.floating, np.integer)) and not isinstance(v, bool)}
+    dist.all_gather_object(parts, num)
+    out = dict(stats)
+    for k in num:
+        vals = [p[k] for p in parts if k in p]
+        out[k] = float(np.sum(vals)) if k in sum_keys else float(np.mean(vals))
+    return out

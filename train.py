@@ -37,9 +37,6 @@ def main():
     torch.cuda.set_device(device)
     world = D.init(device=device)
     rank = D.rank()
-    if world > 1 and args.use_plr:
-        raise NotImplementedError("sharded PLR (single LevelSampler on rank 0) is exercised by bench.py; "
-                                  "the training driver shards PAIRED / DR this round")
     seed(args.seed + rank)
     pg = torch.distributed.group.WORLD if world > 1 else None
     venv, ued_venv = create_parallel_env(args, device=device, env_index_base=rank * args.num_processes)
@@ -56,7 +53,7 @@ def main():
     plr_args = make_plr_args(args, venv.observation_space, venv.action_space) if args.use_plr else None
     runner = AdversarialRunner(args=args, venv=venv, agent=agent, ued_venv=ued_venv, adversary_agent=adversary_agent,
                                adversary_env=adversary_env, flexible_protagonist=False, train=True, plr_args=plr_args,
-                               device=device)
+                               device=device, process_group=pg)
     num_updates = int(args.num_env_steps) // args.num_steps // (args.num_processes * world)
     ckpt = os.path.expandvars(os.path.expanduser(os.path.join(args.log_dir, args.xpid, "model.tar")))
     writer = FileWriter(xpid=args.xpid, xp_args=vars(args), rootdir=args.log_dir) if rank == 0 else None
@@ -72,7 +69,7 @@ def main():
         runner.load_state_dict(torch.load(ckpt, map_location=device, weights_only=False)["runner_state_dict"])
     last, t0 = runner.num_updates, timeit.default_timer()
     for j in range(runner.num_updates, num_updates):
-        stats = runner.run()
+        stats = D.reduce_stats(runner.run())
         test_stats = {}
         if evaluator is not None and (j % args.test_interval == 0 or j == num_updates - 1):
             test_stats = evaluator.evaluate(runner.agents["agent"])
