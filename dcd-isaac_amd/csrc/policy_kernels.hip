@@ -1,0 +1,297 @@
+// policy_kernels.hip — the student's rollout-time policy step (no grad) for gfx950 + C ABI.
+//
+// What the reference does per rollout step in eager PyTorch (models/multigrid_models.py:141-167 `act`,
+// :109-139 base forward; models/common.py:149-156 masked single-step LSTM; models/distributions.py:18-56):
+//   conv3x3(3->F)+ReLU | one-hot(direction)->Linear | (h,c)*mask -> LSTM cell -> actor MLP -> Categorical
+//   .sample()/.log_probs(), critic MLP -> value                           (~45 kernel launches, host-bound)
+// here: TWO kernels around ONE GEMM (the only dense contraction: [B,K]x[K,4H], K = 9F+E+H = 405 — left to
+// rocBLAS through torch.addmm, already at ~90 TFLOP/s fp32 for this shape):
+//   policy_features_kernel   X[b] = [ relu(conv(image[b])) | embed_w[:,dir[b]] + embed_b | h[b]*mask[b] ]
+//   (GEMM)                   gates = X @ [W_ih | W_hh]^T + (b_ih + b_hh)
+//   policy_cell_heads_kernel LSTM pointwise -> (h',c') straight into storage[step+1]; actor/critic hidden
+//                            layers from LDS-resident weights (one output unit per lane); logits, log-softmax,
+//                            Philox inverse-CDF sample (or argmax), log-prob, value -> storage[step]
+// fp32 throughout; results agree with the PyTorch module to fp32 round-off (different summation order), the
+// tolerance is written in tests/test_gpu_policy.py.  The weights stay PyTorch parameters: the kernels read
+// them through the pointers of DcdStudentNet, nothing is copied or cached across optimiser steps.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "../../include/dcd_hip.h"
+#include "dcd_internal.h"
+#include "mg_env.h"
+
+namespace {
+
+constexpr int PB = 256;          // threads per workgroup (4 waves)
+constexpr int FE = 8;            // envs per workgroup, features kernel
+constexpr int HE = 16;           // envs per workgroup, cell+heads kernel (4 per wave)
+constexpr int MAXV = 7, MAXF = 32, MAXH = 256, MAXA = 16;
+
+// ---- features ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PB) policy_features_kernel(DcdStudentNet n, const float* __restrict__ image,
+                                                             const float* __restrict__ direction, const float* __restrict__ hc,
+                                                             const float* __restrict__ masks, float* __restrict__ x, int B) {
+  __shared__ float s_img[FE][3 * MAXV * MAXV];
+  __shared__ float s_w[MAXF * 27 + MAXF];
+  const int tid = threadIdx.x, env0 = blockIdx.x * FE, ne = min(FE, B - env0);
+  const int V = n.V, O = V - 2, OO = O * O, CF = n.F * OO, K = CF + n.E + n.H, IMG = 3 * V * V;
+  for (int q = tid; q < ne * IMG; q += PB) s_img[q / IMG][q % IMG] = image[(size_t)env0 * IMG + q];
+  for (int q = tid; q < n.F * 27; q += PB) s_w[q] = n.conv_w[q];
+  for (int q = tid; q < n.F; q += PB) s_w[MAXF * 27 + q] = n.conv_b[q];
+  __syncthreads();
+  for (int q = tid; q < ne * K; q += PB) {
+    const int e = q / K, k = q - e * K, b = env0 + e;
+    float v;
+    if (k < CF) {                                                    // Conv2d 'valid' + Flatten + ReLU (:45-47)
+      const int f = k / OO, o = k - f * OO, oy = o / O, ox = o - oy * O;
+      const float* w = s_w + f * 27;
+      float acc = s_w[MAXF * 27 + f];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc = fmaf(w[c * 9 + ky * 3 + kx], s_img[e][c * V * V + (oy + ky) * V + ox + kx], acc);
+      v = fmaxf(acc, 0.f);
+    } else if (k < CF + n.E) {                                       // one_hot(dim, direction) @ W^T + b (:123-125)
+      const int j = k - CF;
+      int d = (int)direction[b];
+      d = d < 0 ? 0 : (d >= n.D ? n.D - 1 : d);
+      v = n.embed_w[j * n.D + d] + n.embed_b[j];
+    } else {                                                         // h * masks (common.py:151-153)
+      const int j = k - CF - n.E;
+      v = hc[(size_t)b * 2 * n.H + j] * masks[b];
+    }
+    x[(size_t)b * K + k] = v;
+  }
+}
+
+// ---- LSTM pointwise + heads + sampling ----------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+struct CellArgs {
+  const float* gates; const float* hc_in; const float* masks; float* hc_out;
+  float* value; int64_t* action; float* logp; float* log_dist; float* u_out;
+  uint32_t seed, counter; int64_t env_index_base; int32_t deterministic, B;
+};
+
+// One wave per env at a time (4 envs per wave, 16 per workgroup).  Lane l owns hidden units l, l+64, l+128,
+// l+192 for the cell, then hidden unit l of the stacked [actor | critic] first layers, whose weights sit in
+// LDS transposed ([k][unit]: a wave reads 64 consecutive floats per k, h[k] is an LDS broadcast).
+template <int H>
+__global__ void __launch_bounds__(PB) policy_cell_heads_kernel(DcdStudentNet n, CellArgs a) {
+  extern __shared__ float smem[];
+  const int U = n.A1 + n.C1;                        // <= 64 stacked first-layer units
+  float* s_w1 = smem;                               // [H][64]
+  float* s_b1 = s_w1 + H * 64;                      // [64]
+  float* s_w2 = s_b1 + 64;                          // [MAXA][64]  row a: actor W2[a][:A1]; row NA: critic W2 in cols A1..
+  float* s_b2 = s_w2 + (MAXA + 1) * 64;             // [MAXA+1]
+  float* s_h = s_b2 + 32;                           // [4 waves][H]
+  float* s_t = s_h + 4 * H;                         // [4 waves][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int q = tid; q < H * 64; q += PB) {
+    const int k = q >> 6, u = q & 63;
+    s_w1[q] = u < n.A1 ? n.actor_w1[u * H + k] : (u < U ? n.critic_w1[(u - n.A1) * H + k] : 0.f);
+  }
+  if (tid < 64) s_b1[tid] = tid < n.A1 ? n.actor_b1[tid] : (tid < U ? n.critic_b1[tid - n.A1] : 0.f);
+  for (int q = tid; q < (MAXA + 1) * 64; q += PB) {
+    const int r = q >> 6, u = q & 63;
+    float w = 0.f;
+    if (r < n.NA && u < n.A1) w = n.actor_w2[r * n.A1 + u];
+    else if (r == n.NA && u >= n.A1 && u < U) w = n.critic_w2[u - n.A1];
+    s_w2[q] = w;
+  }
+  if (tid <= n.NA) s_b2[tid] = tid < n.NA ? n.actor_b2[tid] : n.critic_b2[0];
+  __syncthreads();
+  const int env0 = blockIdx.x * HE;
+  float* hb = s_h + wave * H;
+  float* tb = s_t + wave * 64;
+  for (int it = 0; it < HE / 4; ++it) {
+    const int b = env0 + it * 4 + wave;
+    const bool live = b < a.B;
+    if (live) {                                                       // nn.LSTM cell, gate order i,f,g,o
+      const float m = a.masks[b];
+      const float* g = a.gates + (size_t)b * 4 * H;
+      const float* ci = a.hc_in + (size_t)b * 2 * H + H;
+      float* ho = a.hc_out + (size_t)b * 2 * H;
+#pragma unroll
+      for (int q = 0; q < H / 64; ++q) {
+        const int j = lane + 64 * q;
+        const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+        const float c = sigmoidf_(gf) * (ci[j] * m) + sigmoidf_(gi) * tanhf(gg);
+        const float h = sigmoidf_(go) * tanhf(c);
+        ho[j] = h; ho[H + j] = c; hb[j] = h;
+      }
+    }
+    __syncthreads();
+    float acc = s_b1[lane];                                           // Linear(H -> 32) x2 + Tanh (common.py:215-224)
+#pragma unroll 8
+    for (int k = 0; k < H; ++k) acc = fmaf(s_w1[k * 64 + lane], hb[k], acc);
+    tb[lane] = tanhf(acc);
+    __syncthreads();
+    // lanes 0..NA-1: logits; lane NA: value
+    float out = 0.f;
+    if (lane <= n.NA) {
+      out = s_b2[lane];
+      for (int u = 0; u < U; ++u) out = fmaf(s_w2[lane * 64 + u], tb[u], out);
+    }
+    // log-softmax over lanes [0,NA) (Categorical(logits=...) normalises: logits - logsumexp)
+    const float lg = lane < n.NA ? out : -INFINITY;
+    float mx = lg;
+#pragma unroll
+    for (int o = 1; o < MAXA; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float ex = lane < n.NA ? expf(lg - mx) : 0.f, sum = ex;
+#pragma unroll
+    for (int o = 1; o < MAXA; o <<= 1) sum += __shfl_xor(sum, o);
+    const float lsm = lg - mx - logf(sum);
+    const float p = ex / sum;
+    // action: inverse CDF of one Philox uniform per (env, counter), or the first arg max
+    uint32_t r4[4];
+    dcd::philox4x32_10(a.counter, (uint32_t)(a.env_index_base + b), (uint32_t)((a.env_index_base + b) >> 32), 0x504F4C31u,
+                       a.seed, 0x41435421u, r4);
+    const float u01 = (float)(r4[0] >> 8) * (1.0f / 16777216.0f);
+    int act = 0; float cum = 0.f, best = -INFINITY; int arg = 0, chosen = -1;
+    for (int q = 0; q < n.NA; ++q) {
+      const float pq = __shfl(p, q), lq = __shfl(lg, q);
+      cum += pq;
+      if (chosen < 0 && u01 < cum) chosen = q;
+      if (lq > best) { best = lq; arg = q; }
+    }
+    if (chosen < 0) chosen = n.NA - 1;                                // cum rounded below u
+    act = a.deterministic ? arg : chosen;
+    const float lp = __shfl(lsm, act), val = __shfl(out, n.NA);
+    if (live) {
+      if (lane < n.NA) a.log_dist[(size_t)b * n.NA + lane] = lsm;
+      if (lane == 0) {
+        a.value[b] = val; a.action[b] = act; a.logp[b] = lp;
+        if (a.u_out) a.u_out[b] = u01;
+      }
+    }
+  }
+}
+
+// ---- masked LSTM sequence for the PPO update (training path) ---------------------------------------
+// models/common.py:157-207: the flattened (T*N) sequence is cut wherever ANY env has mask 0 and the state is
+// re-masked at each cut == multiplying (h, c) by masks[t] before EVERY step.  Per step the recurrence is one
+// GEMM (gates = xp[t] + hm @ W_hh^T, rocBLAS) and ONE pointwise kernel here; backward likewise.  Everything
+// the backward needs is written by the forward into [T,N,*] buffers (activated gates, cell state, masked h).
+constexpr int LB = 256;
+
+// gates: [N,4H] pre-activation in, ACTIVATED (i,f,g,o) out (saved for backward).  c_prev: C[t-1] (or c0),
+// m_t: masks[t] (applied to c_prev here; h was masked when hm[t] was formed).  m_next: masks[t+1] or NULL.
+__global__ void __launch_bounds__(LB) lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ c_prev,
+                                                          const float* __restrict__ m_t, const float* __restrict__ m_next,
+                                                          float* __restrict__ c_out, float* __restrict__ h_out,
+                                                          float* __restrict__ hm_next, int N, int H) {
+  const int q = blockIdx.x * LB + threadIdx.x;
+  if (q >= N * H) return;
+  const int b = q / H, j = q - b * H;
+  float* g = gates + (size_t)b * 4 * H;
+  const float i = sigmoidf_(g[j]), f = sigmoidf_(g[H + j]), gg = tanhf(g[2 * H + j]), o = sigmoidf_(g[3 * H + j]);
+  const float c = f * (c_prev[q] * m_t[b]) + i * gg;
+  const float h = o * tanhf(c);
+  g[j] = i; g[H + j] = f; g[2 * H + j] = gg; g[3 * H + j] = o;
+  c_out[q] = c; h_out[q] = h;
+  if (hm_next) hm_next[q] = h * m_next[b];
+}
+
+// step t of the backward.  act: activated gates of step t; c_t, c_prev (C[t-1] or c0); m_t = masks[t];
+// dout: grad wrt h_t from the heads; dhm_next: DG[t+1] @ W_hh (raw; NULL at t = T-1), m_next = masks[t+1];
+// dcf_next: dc_{t+1} * f_{t+1} (raw; NULL at T-1).  Writes dgates (pre-activation grads) and dcf = dc_t * f_t.
+__global__ void __launch_bounds__(LB) lstm_seq_bwd_kernel(const float* __restrict__ act, const float* __restrict__ c_t,
+                                                          const float* __restrict__ c_prev, const float* __restrict__ m_t,
+                                                          const float* __restrict__ dout, const float* __restrict__ dhm_next,
+                                                          const float* __restrict__ dcf_next, const float* __restrict__ m_next,
+                                                          const float* __restrict__ dh_last, const float* __restrict__ dc_last,
+                                                          float* __restrict__ dgates, float* __restrict__ dcf, int N, int H) {
+  const int q = blockIdx.x * LB + threadIdx.x;
+  if (q >= N * H) return;
+  const int b = q / H, j = q - b * H;
+  const float* a = act + (size_t)b * 4 * H;
+  const float i = a[j], f = a[H + j], g = a[2 * H + j], o = a[3 * H + j];
+  const float mn = m_next ? m_next[b] : 0.f;
+  float dh = dout ? dout[q] : 0.f, dc = 0.f;
+  if (dhm_next) dh += dhm_next[q] * mn;
+  if (dcf_next) dc += dcf_next[q] * mn;
+  if (dh_last) dh += dh_last[q];
+  if (dc_last) dc += dc_last[q];
+  const float tc = tanhf(c_t[q]);
+  dc += dh * o * (1.f - tc * tc);
+  const float cm = c_prev[q] * m_t[b];
+  float* d = dgates + (size_t)b * 4 * H;
+  d[j] = dc * g * i * (1.f - i);
+  d[H + j] = dc * cm * f * (1.f - f);
+  d[2 * H + j] = dc * i * (1.f - g * g);
+  d[3 * H + j] = dh * tc * o * (1.f - o);
+  dcf[q] = dc * f;
+}
+
+}  // namespace
+
+extern "C" {
+
+static int check_net(const DcdStudentNet* n) {
+  if (!n) return dcd::fail("dcd_policy: net is NULL");
+  if (n->V < 3 || n->V > MAXV || n->F < 1 || n->F > MAXF) return dcd::fail("dcd_policy: unsupported conv geometry V=%d F=%d", n->V, n->F);
+  if (n->H != MAXH) return dcd::fail("dcd_policy: hidden size %d unsupported (256)", n->H);
+  if (n->A1 < 1 || n->C1 < 1 || n->A1 + n->C1 > 64) return dcd::fail("dcd_policy: head widths %d+%d exceed 64", n->A1, n->C1);
+  if (n->NA < 1 || n->NA >= MAXA) return dcd::fail("dcd_policy: %d actions unsupported (<16)", n->NA);
+  if (n->E < 0 || n->D < 1) return dcd::fail("dcd_policy: bad scalar embedding E=%d D=%d", n->E, n->D);
+  return 0;
+}
+
+int dcd_policy_input_width(const DcdStudentNet* n) { return n ? n->F * (n->V - 2) * (n->V - 2) + n->E + n->H : 0; }
+
+int dcd_policy_features(const DcdStudentNet* net, const float* image, const float* direction, const float* hc,
+                        const float* masks, float* x, int32_t B, void* stream) {
+  if (check_net(net)) return 1;
+  if (!image || !direction || !hc || !masks || !x || B <= 0) return dcd::fail("dcd_policy_features: NULL pointer or B <= 0");
+  hipLaunchKernelGGL(policy_features_kernel, dim3((B + FE - 1) / FE), dim3(PB), 0, (hipStream_t)stream, *net, image, direction,
+                     hc, masks, x, B);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_features: launch failed");
+  return 0;
+}
+
+int dcd_policy_cell_heads(const DcdStudentNet* net, const float* gates, const float* hc_in, const float* masks, float* hc_out,
+                          float* value, int64_t* action, float* action_log_prob, float* action_log_dist, float* u_out,
+                          uint32_t seed, uint32_t counter, int64_t env_index_base, int32_t deterministic, int32_t B, void* stream) {
+  if (check_net(net)) return 1;
+  if (!gates || !hc_in || !masks || !hc_out || !value || !action || !action_log_prob || !action_log_dist || B <= 0)
+    return dcd::fail("dcd_policy_cell_heads: NULL pointer or B <= 0");
+  CellArgs a{gates, hc_in, masks, hc_out, value, action, action_log_prob, action_log_dist, u_out, seed, counter, env_index_base,
+             deterministic, B};
+  const size_t lds = sizeof(float) * (MAXH * 64 + 64 + (MAXA + 1) * 64 + 32 + 4 * MAXH + 4 * 64);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_cell_heads_kernel<MAXH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return dcd::fail("dcd_policy_cell_heads: cannot reserve %zu bytes of LDS", lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(policy_cell_heads_kernel<MAXH>, dim3((B + HE - 1) / HE), dim3(PB), lds, (hipStream_t)stream, *net, a);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_cell_heads: launch failed");
+  return 0;
+}
+
+int dcd_lstm_seq_fwd_step(float* gates, const float* c_prev, const float* m_t, const float* m_next, float* c_out, float* h_out,
+                          float* hm_next, int32_t N, int32_t H, void* stream) {
+  if (!gates || !c_prev || !m_t || !c_out || !h_out || N <= 0 || H <= 0) return dcd::fail("dcd_lstm_seq_fwd_step: NULL pointer or empty");
+  if (hm_next && !m_next) return dcd::fail("dcd_lstm_seq_fwd_step: hm_next needs m_next");
+  hipLaunchKernelGGL(lstm_seq_fwd_kernel, dim3((N * H + LB - 1) / LB), dim3(LB), 0, (hipStream_t)stream, gates, c_prev, m_t, m_next,
+                     c_out, h_out, hm_next, N, H);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_lstm_seq_fwd_step: launch failed");
+  return 0;
+}
+
+int dcd_lstm_seq_bwd_step(const float* act, const float* c_t, const float* c_prev, const float* m_t, const float* dout,
+                          const float* dhm_next, const float* dcf_next, const float* m_next, const float* dh_last,
+                          const float* dc_last, float* dgates, float* dcf, int32_t N, int32_t H, void* stream) {
+  if (!act || !c_t || !c_prev || !m_t || !dgates || !dcf || N <= 0 || H <= 0) return dcd::fail("dcd_lstm_seq_bwd_step: NULL pointer or empty");
+  if ((dhm_next || dcf_next) && !m_next) return dcd::fail("dcd_lstm_seq_bwd_step: recurrent grads need m_next");
+  hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3((N * H + LB - 1) / LB), dim3(LB), 0, (hipStream_t)stream, act, c_t, c_prev, m_t, dout,
+                     dhm_next, dcf_next, m_next, dh_last, dc_last, dgates, dcf, N, H);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_lstm_seq_bwd_step: launch failed");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+"""Rollout-time student policy step on the HIP path (dcd_policy_* of include/dcd_hip.h).
+
+`StudentActor` wraps a `MultigridNetwork` (student shape: image + direction, one conv, LSTM-256, one tanh
+layer per head) and performs `act` + `storage.insert_policy` for a whole env batch with two HIP kernels and
+one rocBLAS GEMM, writing straight into the RolloutStorage slices — the eager PyTorch path costs ~45 launches
+per step and is host-bound (0.63 ms per step at B = 4096; this path: see DESIGN.md §5).
+
+The network's parameters stay ordinary PyTorch parameters (PPO trains them through the PyTorch modules); this
+class only reads them.  `try_create` returns None when the network is not of the supported shape — callers
+then use the PyTorch modules on the GPU (same results, more launches); there is no CPU path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import DcdHipError, check, lib, ptr, stream_ptr
+
+
+class StudentNet(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("conv_w", "conv_b", "embed_w", "embed_b", "actor_w1", "actor_b1", "actor_w2",
+                                          "actor_b2", "critic_w1", "critic_b1", "critic_w2", "critic_b2")] + \
+               [(k, C.c_int32) for k in ("V", "F", "E", "D", "H", "A1", "C1", "NA")]
+
+
+def enabled():
+    return os.environ.get("DCD_FUSED_ACT", "1") != "0"
+
+
+class StudentActor:
+    def __init__(self, net, num_envs, seed=0, env_index_base=0):
+        self.net, self.B = net, int(num_envs)
+        self.seed, self.env_index_base = int(seed) & 0xFFFFFFFF, int(env_index_base)
+        self.counter = 0
+        conv = net.image_conv[0]
+        lstm = net.rnn.rnn
+        self.H = lstm.hidden_size
+        dev = conv.weight.device
+        self.device = dev
+        V = int(round((net.image_embedding_size / conv.out_channels) ** 0.5)) + conv.kernel_size[0] - 1
+        a1, a2 = net.actor[0][0], net.actor[1].linear
+        c1, c2 = net.critic[0][0], net.critic[1]
+        self._params = [conv.weight, conv.bias, net.scalar_embed.weight, net.scalar_embed.bias, a1.weight, a1.bias,
+                        a2.weight, a2.bias, c1.weight, c1.bias, c2.weight, c2.bias]
+        self._dims = dict(V=V, F=conv.out_channels, E=net.scalar_embed.out_features, D=net.scalar_embed.in_features,
+                          H=self.H, A1=a1.out_features, C1=c1.out_features, NA=a2.out_features)
+        self._lstm = lstm
+        self.K = self._dims["F"] * (V - 2) ** 2 + self._dims["E"] + self.H
+        self.x = torch.empty((self.B, self.K), device=dev)
+        self.gates = torch.empty((self.B, 4 * self.H), device=dev)
+        self._struct = None
+        self._w_version = None
+        self.refresh()
+
+    # ---- construction ------------------------------------------------------------------------
+    @staticmethod
+    def supported(net):
+        try:
+            from models.multigrid_models import MultigridNetwork
+        except ImportError:
+            return False
+        if not isinstance(net, MultigridNetwork) or net.random or net.rnn is None or not net.rnn.is_lstm:
+            return False
+        conv = net.image_conv[0]
+        if not conv.weight.is_cuda or conv.kernel_size != (3, 3) or conv.in_channels != 3 or conv.out_channels > 32:
+            return False
+        if net.scalar_embed is None or net.xy_dim or net.preprocessed_input_size != net.image_embedding_size + net.scalar_embed.out_features:
+            return False                                            # random_z / xy inputs: teacher-shaped nets
+        if net.rnn.rnn.hidden_size != 256 or net.rnn.rnn.num_layers != 1:
+            return False
+        if len(net.actor[0]) != 2 or len(net.critic[0]) != 2:        # exactly one Linear+Tanh per head
+            return False
+        a1, c1, a2 = net.actor[0][0], net.critic[0][0], net.actor[1].linear
+        return a1.out_features + c1.out_features <= 64 and a2.out_features < 16 and net.critic[1].out_features == 1
+
+    @classmethod
+    def try_create(cls, net, num_envs, seed=0, env_index_base=0):
+        if not enabled() or not cls.supported(net):
+            return None
+        return cls(net, num_envs, seed=seed, env_index_base=env_index_base)
+
+    def refresh(self):
+        """Re-read parameter pointers and rebuild the stacked LSTM weight [4H, K-H | H] when the optimiser
+        has stepped (in-place updates keep pointers but change values, so the stacked copy is refreshed
+        whenever any LSTM parameter's version counter moved)."""
+        l = self._lstm
+        ver = tuple(p._version for p in (l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0)) + \
+            tuple(p.data_ptr() for p in self._params)
+        if ver == self._w_version:
+            return
+        with torch.no_grad():
+            self.w_t = torch.cat([l.weight_ih_l0, l.weight_hh_l0], dim=1).t().contiguous()        # [K, 4H]
+            self.bias = (l.bias_ih_l0 + l.bias_hh_l0).contiguous()
+        s = StudentNet()
+        for name, p in zip([f[0] for f in StudentNet._fields_[:12]], self._params):
+            setattr(s, name, ptr(p.detach(), torch.float32, name=name).value)
+        for k, v in self._dims.items():
+            setattr(s, k, v)
+        self._struct = s
+        self._w_version = ver
+        if lib().dcd_policy_input_width(C.byref(s)) != self.K:
+            raise DcdHipError("dcd_policy_input_width disagrees with the network's LSTM input size")
+
+    # ---- one step ----------------------------------------------------------------------------
+    def act_into(self, image, direction, hc_in, masks, hc_out, value, action, log_prob, log_dist, deterministic=False,
+                 u_out=None):
+        """All arguments are slices of a RolloutStorage (contiguous CUDA tensors):
+        image [B,3,V,V], direction [B,1], hc_in/hc_out [B,2H], masks [B,1] -> value [B,1], action int64 [B,1],
+        log_prob [B,1], log_dist [B,NA]."""
+        B, s = self.B, self._struct
+        L = lib()
+        check(L.dcd_policy_features(C.byref(s), ptr(image, torch.float32, B * 3 * self._dims["V"] ** 2, "image"),
+                                    ptr(direction, torch.float32, B, "direction"), ptr(hc_in, torch.float32, B * 2 * self.H, "hc_in"),
+                                    ptr(masks, torch.float32, B, "masks"), ptr(self.x), C.c_int32(B), stream_ptr()))
+        torch.addmm(self.bias, self.x, self.w_t, out=self.gates)
+        check(L.dcd_policy_cell_heads(C.byref(s), ptr(self.gates), ptr(hc_in), ptr(masks), ptr(hc_out, torch.float32, B * 2 * self.H, "hc_out"),
+                                      ptr(value, torch.float32, B, "value"), ptr(action, torch.int64, B, "action"),
+                                      ptr(log_prob, torch.float32, B, "log_prob"),
+                                      ptr(log_dist, torch.float32, B * self._dims["NA"], "log_dist"),
+                                      ptr(u_out, torch.float32, B, "u_out") if u_out is not None else None,
+                                      C.c_uint32(self.seed), C.c_uint32(self.counter & 0xFFFFFFFF), C.c_int64(self.env_index_base),
+                                      C.c_int32(int(deterministic)), C.c_int32(B), stream_ptr()))
+        self.counter += 1
+
+    def act_storage(self, st, step, deterministic=False):
+        """`agent.act(obs[step], h[step], masks[step])` + `storage.insert_policy(...)` (adversarial_runner.py:506-517,
+        algos/storage.py:155-185) without leaving the device: writes value_preds[step], actions[step],
+        action_log_probs[step], action_log_dist[step], recurrent_hidden_states[step+1]."""
+        self.act_into(st.obs["image"][step], st.obs["direction"][step], st.recurrent_hidden_states[step], st.masks[step],
+                      st.recurrent_hidden_states[step + 1], st.value_preds[step], st.actions[step], st.action_log_probs[step],
+                      st.action_log_dist[step], deterministic=deterministic)

@@ -375,6 +375,23 @@ class AdversarialRunner:
         agent.storage.step = 0
         self.venv.raise_errors()
 
+    def _fused_actor(self, agent):
+        """dcd_hip.policy.StudentActor for this agent's network (act + insert_policy as two HIP kernels and one
+        GEMM), or None when the network is not student-shaped / DCD_FUSED_ACT=0: then the PyTorch modules run."""
+        fa = getattr(agent, "_fused_actor", False)
+        if fa is False:
+            from dcd_hip.policy import StudentActor
+            k = [a for a in self.agents.values() if a is not None].index(agent) if agent in self.agents.values() else 0
+            fa = None
+            if self.device.type == "cuda":
+                fa = StudentActor.try_create(agent.actor_critic, self.args.num_processes,
+                                             seed=(self.args.seed * 2654435761 + 97 * k + 1) & 0xFFFFFFFF,
+                                             env_index_base=getattr(self.venv, "env_index_base", 0))
+            agent._fused_actor = fa
+        if fa is not None and agent.actor_critic.random:
+            return None
+        return fa
+
     def _student_rollout_body(self, agent, num_steps, t0, t1, level_replay, level_sampler, rollout_info):
         args, st, venv = self.args, agent.storage, self.venv
         reset_random = self.is_dr and not args.use_plr
@@ -382,12 +399,21 @@ class AdversarialRunner:
             venv.reset_agent_device(st.student_obs_out(0))
         st.step = t0
         track_seeds = level_sampler is not None
+        fused = self._fused_actor(agent) if self.is_discrete_actions else None
+        if fused is not None:
+            fused.refresh()
         for step in range(t0, t1):
-            with torch.no_grad():
-                value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step),
-                                                         st.masks[step])
-                log_prob = log_dist.gather(-1, action) if self.is_discrete_actions else log_dist
-            st.insert_policy(hxs, action, log_prob, log_dist, value, self._seeds_dev if track_seeds else None)
+            if fused is not None:
+                fused.act_storage(st, step)
+                if track_seeds:
+                    st.level_seeds[step].copy_(self._seeds_dev)
+                action = st.actions[step]
+            else:
+                with torch.no_grad():
+                    value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step),
+                                                             st.masks[step])
+                    log_prob = log_dist.gather(-1, action) if self.is_discrete_actions else log_dist
+                st.insert_policy(hxs, action, log_prob, log_dist, value, self._seeds_dev if track_seeds else None)
             last = step >= num_steps - 1
             venv.step_env_device(action.view(-1), st.step_out(step), reset_random=reset_random,
                                  last_step=last and st.use_proper_time_limits)

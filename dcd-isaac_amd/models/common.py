@@ -97,6 +97,72 @@ def _valid_conv_gemm(self, x):
 Conv2d_tf._valid_conv_gemm = _valid_conv_gemm
 
 
+def _fused_lstm_enabled():
+    import os
+    return os.environ.get("DCD_FUSED_LSTM", "1") != "0"
+
+
+class MaskedLSTMSequence(torch.autograd.Function):
+    """The masked LSTM over a whole rollout (common.py:157-207: state multiplied by masks[t] before every step)
+    as ONE autograd node: per time step one rocBLAS GEMM + one HIP pointwise kernel forward
+    (dcd_lstm_seq_fwd_step) and the same backward (dcd_lstm_seq_bwd_step), instead of ~14 + ~26 elementwise
+    launches per step through autograd.  d W_hh and d xp come out of two GEMMs over the whole [T*N] batch.
+
+    xp: [T,N,4H] input projection (+ both biases); h0, c0: [N,H]; masks: [T,N]; w_hh: [4H,H]."""
+
+    @staticmethod
+    def forward(ctx, xp, h0, c0, masks, w_hh):
+        import ctypes as C
+        from dcd_hip import check, lib, ptr, stream_ptr
+        T, N, G = xp.shape
+        H = G // 4
+        xp, masks, c0 = xp.contiguous(), masks.contiguous().float(), c0.contiguous()
+        act = torch.empty_like(xp)
+        cs = torch.empty((T, N, H), device=xp.device)
+        out = torch.empty((T, N, H), device=xp.device)
+        hm = torch.empty((T, N, H), device=xp.device)
+        torch.mul(h0, masks[0].unsqueeze(1), out=hm[0])
+        w_hh_t = w_hh.t()
+        L, st = lib(), stream_ptr()
+        for t in range(T):
+            torch.addmm(xp[t], hm[t], w_hh_t, out=act[t])
+            nxt = t + 1 < T
+            check(L.dcd_lstm_seq_fwd_step(ptr(act[t]), ptr(cs[t - 1] if t else c0), ptr(masks[t]), ptr(masks[t + 1]) if nxt else None,
+                                          ptr(cs[t]), ptr(out[t]), ptr(hm[t + 1]) if nxt else None, C.c_int32(N), C.c_int32(H), st))
+        ctx.save_for_backward(act, cs, hm, c0, masks, w_hh)
+        return out, out[T - 1].clone(), cs[T - 1].clone()
+
+    @staticmethod
+    def backward(ctx, d_out, d_hT, d_cT):
+        import ctypes as C
+        from dcd_hip import check, lib, ptr, stream_ptr
+        act, cs, hm, c0, masks, w_hh = ctx.saved_tensors
+        T, N, G = act.shape
+        H = G // 4
+        dg = torch.empty_like(act)
+        dhm = torch.empty((N, H), device=act.device)
+        dcf = [torch.empty((N, H), device=act.device) for _ in range(2)]
+        d_out = d_out.contiguous() if d_out is not None else None
+        d_hT = d_hT.contiguous() if d_hT is not None else None
+        d_cT = d_cT.contiguous() if d_cT is not None else None
+        L, st = lib(), stream_ptr()
+        for t in range(T - 1, -1, -1):
+            last = t == T - 1
+            cur, prev = dcf[t & 1], dcf[(t + 1) & 1]
+            check(L.dcd_lstm_seq_bwd_step(ptr(act[t]), ptr(cs[t]), ptr(cs[t - 1] if t else c0), ptr(masks[t]),
+                                          ptr(d_out[t]) if d_out is not None else None,
+                                          None if last else ptr(dhm), None if last else ptr(prev), None if last else ptr(masks[t + 1]),
+                                          ptr(d_hT) if (last and d_hT is not None) else None,
+                                          ptr(d_cT) if (last and d_cT is not None) else None,
+                                          ptr(dg[t]), ptr(cur), C.c_int32(N), C.c_int32(H), st))
+            torch.mm(dg[t], w_hh, out=dhm)
+        m0 = masks[0].unsqueeze(1)
+        d_h0 = dhm * m0 if ctx.needs_input_grad[1] else None
+        d_c0 = dcf[0] * m0 if ctx.needs_input_grad[2] else None
+        d_w = dg.view(T * N, G).t() @ hm.view(T * N, H) if ctx.needs_input_grad[4] else None
+        return dg, d_h0, d_c0, None, d_w
+
+
 class RNN(nn.Module):
     """Masked LSTM/GRU (common.py:109-209): a single step multiplies the state by `masks` before the
     cell; a flattened (T*N) sequence is cut at every step where ANY env has mask 0 and the state is
@@ -140,11 +206,21 @@ class RNN(nn.Module):
             return h, (h, c)
         N = h.size(0)
         T = x.size(0) // N
+        xp = torch.addmm(r.bias_ih_l0 + r.bias_hh_l0, x, r.weight_ih_l0.t()).view(T, N, 4 * H)
+        if _fused_lstm_enabled():
+            out, hT, cT = MaskedLSTMSequence.apply(xp, h, c, masks.view(T, N), r.weight_hh_l0)
+            return out.view(T * N, H), (hT, cT)
+        return self._lstm_cuda_unfused(xp, h, c, masks, T, N)
+
+    def _lstm_cuda_unfused(self, xp, h, c, masks, T, N):
+        """The same recurrence composed from PyTorch ops (~40 launches per step with autograd); kept as the
+        reference the fused path is tested against (DCD_FUSED_LSTM=0 selects it)."""
+        H = self._hidden_size
         # unbind (ONE UnbindBackward that stacks the per-step grads) — indexing xp[t] in the loop would make
         # every step's backward materialise a full [T,N,4H] zero tensor (4.3 GB at T=256, N=4096)
-        xp = torch.addmm(r.bias_ih_l0 + r.bias_hh_l0, x, r.weight_ih_l0.t()).view(T, N, 4 * H).unbind(0)
+        xp = xp.unbind(0)
         m = masks.view(T, N, 1).unbind(0)
-        w_hh_t = r.weight_hh_l0.t()
+        w_hh_t = self.rnn.weight_hh_l0.t()
         outs = []
         for t in range(T):
             h, c = h * m[t], c * m[t]

@@ -294,6 +294,65 @@ int dcd_rollout_return_stats(const float* ep_ret, const uint8_t* info, int32_t T
 int dcd_env_return(const float* agent_mean, const float* agent_max, const float* adv_mean,
                    const float* adv_max, float* out, int32_t B, int32_t mode, void* stream);
 
+/* ---- student policy step for rollouts (no grad) -------------------------------- */
+/* Device pointers to the fp32 parameters of the student MultigridNetwork
+ * (models/multigrid_models.py:45-88, util/make_agent.py:38-47): they stay PyTorch
+ * parameters, the kernels read them in place on every call. */
+typedef struct DcdStudentNet {
+  const float* conv_w;     /* image_conv.0.weight  [F,3,3,3]                      */
+  const float* conv_b;     /* image_conv.0.bias    [F]                            */
+  const float* embed_w;    /* scalar_embed.weight  [E,D]   (E=scalar_fc, D=scalar_dim) */
+  const float* embed_b;    /* scalar_embed.bias    [E]                            */
+  const float* actor_w1;   /* actor.0.0.weight     [A1,H]  (+Tanh)                */
+  const float* actor_b1;
+  const float* actor_w2;   /* actor.1.linear.weight [NA,A1] (Categorical)          */
+  const float* actor_b2;
+  const float* critic_w1;  /* critic.0.0.weight    [C1,H]  (+Tanh)                */
+  const float* critic_b1;
+  const float* critic_w2;  /* critic.1.weight      [1,C1]                         */
+  const float* critic_b2;
+  int32_t V, F, E, D, H, A1, C1, NA;
+} DcdStudentNet;
+/* K = F*(V-2)^2 + E + H: width of the LSTM's stacked input row [features | h*mask]. */
+int dcd_policy_input_width(const DcdStudentNet* net);
+/* First half of MultigridNetwork._forward_base (multigrid_models.py:109-139) and of the masked
+ * single-step LSTM (models/common.py:149-153): x[b] = [relu(conv(image[b])) flattened CHW |
+ * scalar_embed(one_hot(direction[b])) | h[b]*masks[b]], x: float[B,K].  image: float[B,3,V,V],
+ * direction: float[B], hc: float[B,2H] (h | c: RolloutStorage.recurrent_hidden_states[step]),
+ * masks: float[B].  The caller then forms gates = x @ [W_ih | W_hh]^T + (b_ih + b_hh) (one GEMM). */
+int dcd_policy_features(const DcdStudentNet* net, const float* image, const float* direction, const float* hc,
+                        const float* masks, float* x, int32_t B, void* stream);
+/* Rest of `act` (multigrid_models.py:141-167): LSTM cell on gates float[B,4H] (order i,f,g,o) with
+ * c = hc_in[:,H:]*masks -> hc_out float[B,2H] (storage.recurrent_hidden_states[step+1]); actor / critic
+ * heads; action_log_dist float[B,NA] = normalised logits (FixedCategorical.logits); action int64[B] sampled
+ * by inverse CDF from one Philox4x32-10 uniform per env, key (seed,'ACT!'), counter (counter, global env
+ * index) — or the first arg max when deterministic; action_log_prob float[B]; value float[B].
+ * u_out (optional, tests): the uniform used.  The reference samples with torch.multinomial on the global
+ * torch RNG; any exact sampler of the same distribution is equivalent. */
+int dcd_policy_cell_heads(const DcdStudentNet* net, const float* gates, const float* hc_in, const float* masks,
+                          float* hc_out, float* value, int64_t* action, float* action_log_prob,
+                          float* action_log_dist, float* u_out, uint32_t seed, uint32_t counter,
+                          int64_t env_index_base, int32_t deterministic, int32_t B, void* stream);
+
+/* ---- masked LSTM sequence of the PPO update (models/common.py:157-207) ------------------ */
+/* The reference cuts the flattened (T*N) sequence wherever ANY env has mask 0 and re-masks the state at each
+ * cut — the same function as multiplying (h, c) by masks[t] before every step.  One step of that recurrence
+ * is a GEMM (caller: gates = xp[t] + hm[t] @ W_hh^T) plus this pointwise kernel; the backward step likewise
+ * (caller: dhm = dgates @ W_hh).  Gate order i,f,g,o (nn.LSTM).
+ * fwd: gates float[N,4H] pre-activation in / ACTIVATED out (kept for the backward); c_prev float[N,H] = C[t-1]
+ * (unmasked; multiplied by m_t float[N] here); c_out, h_out float[N,H]; hm_next float[N,H] = h_out * m_next
+ * (the next step's GEMM operand; NULL with m_next at the last step). */
+int dcd_lstm_seq_fwd_step(float* gates, const float* c_prev, const float* m_t, const float* m_next, float* c_out,
+                          float* h_out, float* hm_next, int32_t N, int32_t H, void* stream);
+/* bwd of step t: act = activated gates, c_t, c_prev (unmasked C[t-1]), m_t; dout = dL/dh_t from the heads (or
+ * NULL); dhm_next = dgates[t+1] @ W_hh and dcf_next = dcf[t+1], both multiplied by m_next = masks[t+1] here
+ * (all three NULL at t = T-1); dh_last / dc_last: grads of the returned final state (NULL if unused).
+ * Writes dgates float[N,4H] (pre-activation grads: d xp[t]) and dcf float[N,H] = dL/dc_t * f_t. */
+int dcd_lstm_seq_bwd_step(const float* act, const float* c_t, const float* c_prev, const float* m_t,
+                          const float* dout, const float* dhm_next, const float* dcf_next, const float* m_next,
+                          const float* dh_last, const float* dc_last, float* dgates, float* dcf, int32_t N,
+                          int32_t H, void* stream);
+
 /* ---- synthetic workload helpers (bench / tests only) ------------- */
 /* actions[t,i] = mulhi(philox(key=(seed, env_index_base+i), ctr=(t0+t,0,0,0))[0], num_actions);
  * actions: int64[T,B] */

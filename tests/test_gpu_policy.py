@@ -1,0 +1,203 @@
+"""-m gpu: the fused rollout-time policy step (dcd_policy_features + GEMM + dcd_policy_cell_heads) against the
+PyTorch MultigridNetwork it reads its weights from (reference semantics: models/multigrid_models.py:109-167,
+models/common.py:149-156, models/distributions.py:18-56).
+
+Tolerance: fp32 round-off of differently ordered sums — |diff| <= 3e-6 on values / log-probs / hidden state
+(|h|,|c| < 1 by construction; logits of a freshly initialised policy head are O(1e-2))."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ATOL = 3e-6
+
+
+def _net(seed=0):
+    from envs import spaces
+    from models import MultigridNetwork
+    torch.manual_seed(seed)
+    obs = {"image": spaces.Box(0, 255, (3, 5, 5), "uint8"), "direction": spaces.Box(0, 3, (1,), "uint8")}
+    net = MultigridNetwork(obs, spaces.Discrete(7), scalar_fc=5, scalar_dim=4, recurrent_arch="lstm", recurrent_hidden_size=256)
+    with torch.no_grad():                                            # un-degenerate the heads (init gain 0.01, zero biases)
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+        net.actor[1].linear.weight.mul_(60.0)
+    return net.to(DEV)
+
+
+def _inputs(B, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    image = (torch.randint(0, 11, (B, 3, 5, 5), generator=g).float() / 10.0).to(DEV)
+    direction = torch.randint(0, 4, (B, 1), generator=g).float().to(DEV)
+    hc = (torch.rand(B, 512, generator=g) * 2 - 1).to(DEV)
+    masks = (torch.rand(B, 1, generator=g) > 0.2).float().to(DEV)
+    return image, direction, hc, masks
+
+
+def _fused(net, B, image, direction, hc, masks, deterministic, counter=0, seed=11):
+    from dcd_hip.policy import StudentActor
+    assert StudentActor.supported(net)
+    fa = StudentActor(net, B, seed=seed, env_index_base=1000)
+    fa.counter = counter
+    out = dict(hc=torch.zeros(B, 512, device=DEV), value=torch.zeros(B, 1, device=DEV),
+               action=torch.zeros(B, 1, dtype=torch.int64, device=DEV), logp=torch.zeros(B, 1, device=DEV),
+               log_dist=torch.zeros(B, 7, device=DEV), u=torch.zeros(B, device=DEV))
+    fa.act_into(image, direction, hc, masks, out["hc"], out["value"], out["action"], out["logp"], out["log_dist"],
+                deterministic=deterministic, u_out=out["u"])
+    torch.cuda.synchronize()
+    return fa, out
+
+
+@pytest.mark.parametrize("B", [1, 37, 4096])
+def test_fused_act_matches_module(B):
+    net = _net()
+    image, direction, hc, masks = _inputs(B)
+    with torch.no_grad():
+        value, action, log_dist, (h, c) = net.act({"image": image, "direction": direction}, (hc[:, :256], hc[:, 256:]), masks,
+                                                  deterministic=True)
+    fa, out = _fused(net, B, image, direction, hc, masks, deterministic=True)
+    assert (out["hc"][:, :256] - h).abs().max().item() <= ATOL and (out["hc"][:, 256:] - c).abs().max().item() <= ATOL
+    assert (out["value"] - value).abs().max().item() <= ATOL
+    assert (out["log_dist"] - log_dist).abs().max().item() <= ATOL
+    assert torch.allclose(out["log_dist"].exp().sum(-1), torch.ones(B, device=DEV), atol=1e-5)
+    top2 = log_dist.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-5                          # arg max unambiguous at fp32 round-off
+    assert clear.float().mean().item() > 0.9
+    assert torch.equal(out["action"][clear], action[clear])
+    assert torch.equal(out["logp"], out["log_dist"].gather(-1, out["action"]))
+
+
+def test_sampling_is_inverse_cdf_of_its_own_distribution():
+    B = 4096
+    net = _net(3)
+    image, direction, hc, masks = _inputs(B, 5)
+    fa, out = _fused(net, B, image, direction, hc, masks, deterministic=False, counter=7)
+    p = out["log_dist"].double().exp().cpu().numpy()
+    cum = np.cumsum(p, axis=1)
+    a = out["action"].cpu().numpy()[:, 0]
+    u = out["u"].double().cpu().numpy()
+    assert (u >= 0).all() and (u < 1).all() and 0.45 < u.mean() < 0.55
+    lo = np.where(a > 0, cum[np.arange(B), np.maximum(a - 1, 0)], 0.0)
+    hi = cum[np.arange(B), a]
+    assert (u >= lo - 1e-6).all() and (u < hi + 1e-6).all()
+    assert torch.equal(out["logp"], out["log_dist"].gather(-1, out["action"]))
+    # a different counter / seed / env gives different draws; the same triple repeats
+    _, again = _fused(net, B, image, direction, hc, masks, deterministic=False, counter=7)
+    _, other = _fused(net, B, image, direction, hc, masks, deterministic=False, counter=8)
+    assert torch.equal(again["u"], out["u"]) and not torch.equal(other["u"], out["u"])
+    assert len(np.unique(out["u"].cpu().numpy())) > 0.99 * B
+
+
+def test_sampling_frequencies():
+    """One observation replicated over 4096 envs x 8 counters: empirical action frequencies vs probabilities."""
+    B = 4096
+    net = _net(4)
+    image, direction, hc, masks = (t[:1].expand(B, *t.shape[1:]).contiguous() for t in _inputs(1, 9))
+    counts = np.zeros(7)
+    for k in range(8):
+        _, out = _fused(net, B, image, direction, hc, masks, deterministic=False, counter=k)
+        counts += np.bincount(out["action"].cpu().numpy()[:, 0], minlength=7)
+    p = out["log_dist"][0].double().exp().cpu().numpy()
+    n = counts.sum()
+    z = (counts - n * p) / np.sqrt(n * p * (1 - p) + 1e-12)
+    assert np.abs(z).max() < 5.0, (counts / n, p)
+
+
+def test_act_storage_fills_the_reference_fields_and_tracks_optimizer_steps():
+    from algos import RolloutStorage
+    from envs import spaces
+    from dcd_hip.policy import StudentActor
+    B, T = 64, 4
+    net = _net(6)
+    obs = {"image": spaces.Box(0, 255, (3, 5, 5), "uint8"), "direction": spaces.Box(0, 3, (1,), "uint8")}
+    st = RolloutStorage(net, T, B, obs, spaces.Discrete(7), 256, recurrent_arch="lstm", use_proper_time_limits=True, device=DEV)
+    image, direction, hc, masks = _inputs(B, 2)
+    st.obs["image"][1].copy_(image); st.obs["direction"][1].copy_(direction)
+    st.recurrent_hidden_states[1].copy_(hc); st.masks[1].copy_(masks)
+    fa = StudentActor.try_create(net, B, seed=1)
+    fa.act_storage(st, 1, deterministic=True)
+    with torch.no_grad():
+        value, action, log_dist, (h, c) = net.act(st.get_obs(1), st.get_recurrent_hidden_state(1), st.masks[1], deterministic=True)
+    assert (st.value_preds[1] - value).abs().max().item() <= ATOL
+    assert (st.action_log_dist[1] - log_dist).abs().max().item() <= ATOL
+    assert (st.recurrent_hidden_states[2] - torch.cat([h, c], -1)).abs().max().item() <= ATOL
+    assert torch.equal(st.action_log_probs[1], st.action_log_dist[1].gather(-1, st.actions[1]))
+    # an optimiser step changes the weights in place: the next act must see them (LSTM copy refreshed, heads read in place)
+    opt = torch.optim.SGD(net.parameters(), lr=0.5)
+    v, lp, ent, _ = net.evaluate_actions(st.get_obs(1), st.get_recurrent_hidden_state(1), st.masks[1], st.actions[1])
+    (v.mean() + lp.mean()).backward()
+    opt.step()
+    fa.refresh()
+    fa.act_storage(st, 1, deterministic=True)
+    with torch.no_grad():
+        value2, _, log_dist2, (h2, c2) = net.act(st.get_obs(1), st.get_recurrent_hidden_state(1), st.masks[1], deterministic=True)
+    assert (value2 - value).abs().max().item() > 1e-4                 # the step did change the function
+    assert (st.value_preds[1] - value2).abs().max().item() <= ATOL
+    assert (st.recurrent_hidden_states[2] - torch.cat([h2, c2], -1)).abs().max().item() <= ATOL
+
+
+def test_unsupported_networks_fall_back_to_the_pytorch_modules():
+    from envs import spaces
+    from models import MultigridNetwork
+    from dcd_hip.policy import StudentActor
+    obs = {"image": spaces.Box(0, 255, (3, 15, 15), "uint8"), "time_step": spaces.Box(0, 27, (1,), "uint8"),
+           "random_z": spaces.Box(0, 1, (50,), "float32")}
+    teacher = MultigridNetwork(obs, spaces.Discrete(169), conv_filters=128, scalar_fc=10, scalar_dim=28, random_z_dim=50,
+                               recurrent_arch="lstm", recurrent_hidden_size=256).to(DEV)
+    assert not StudentActor.supported(teacher) and StudentActor.try_create(teacher, 8) is None
+
+
+# ---- fused masked LSTM sequence (PPO update path) ---------------------------------------------------
+@pytest.mark.parametrize("T,N", [(1, 5), (7, 33), (48, 256)])
+def test_fused_lstm_sequence_matches_composed_ops(T, N, monkeypatch):
+    """MaskedLSTMSequence (GEMM + dcd_lstm_seq_*_step per time step) vs the same recurrence composed from PyTorch
+    ops with autograd (RNN._lstm_cuda_unfused, itself checked against nn.LSTM chunking on the CPU): outputs,
+    final state and every gradient.  Tolerance: fp32 round-off of the differently fused pointwise math,
+    relative to each tensor's scale (gradients sum over T*N terms)."""
+    from models.common import RNN
+    torch.manual_seed(T * 100 + N)
+    K, H = 149, 256
+    rnn = RNN(K, H, arch="lstm").to(DEV)
+    x = torch.randn(T * N, K, device=DEV, requires_grad=True)
+    h0 = (torch.rand(N, H, device=DEV) * 2 - 1).requires_grad_()
+    c0 = (torch.rand(N, H, device=DEV) * 2 - 1).requires_grad_()
+    masks = (torch.rand(T * N, 1, device=DEV) > 0.15).float()
+    w_out = torch.randn(T * N, H, device=DEV)
+    w_h, w_c = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)
+
+    def run(fused):
+        monkeypatch.setenv("DCD_FUSED_LSTM", "1" if fused else "0")
+        for p in list(rnn.parameters()) + [x, h0, c0]:
+            p.grad = None
+        y, (hT, cT) = rnn(x, (h0, c0), masks)
+        ((y * w_out).sum() + (hT * w_h).sum() + (cT * w_c).sum()).backward()
+        return [y.detach(), hT.detach(), cT.detach(), x.grad.clone(), h0.grad.clone(), c0.grad.clone()] + \
+               [p.grad.clone() for p in rnn.parameters()]
+
+    ref, got = run(False), run(True)
+    names = ["y", "hT", "cT", "dx", "dh0", "dc0"] + [n for n, _ in rnn.named_parameters()]
+    for n, a, b in zip(names, ref, got):
+        scale = max(a.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-6, (n, (a - b).abs().max().item(), scale)
+
+
+def test_fused_lstm_sequence_without_final_state_grads(monkeypatch):
+    """evaluate_actions ignores the returned state: its grads arrive as None."""
+    from models.common import RNN
+    torch.manual_seed(0)
+    rnn = RNN(20, 256, arch="lstm").to(DEV)
+    x = torch.randn(6 * 8, 20, device=DEV)
+    masks = torch.ones(6 * 8, 1, device=DEV)
+    masks[16:24] = 0
+    h0 = c0 = torch.zeros(8, 256, device=DEV)
+    outs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("DCD_FUSED_LSTM", fused)
+        rnn.zero_grad()
+        y, _ = rnn(x, (h0, c0), masks)
+        y.pow(2).sum().backward()
+        outs.append([y.detach()] + [p.grad.clone() for p in rnn.parameters()])
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1e-6) + 1e-6

@@ -21,15 +21,28 @@ outb = eng.step_buffers(u8=False)
 names = ["init_luts", "stage_in", "logic", "dyn store+writeback", "render_emit", "term emit"]
 import numpy as np
 acc = []
-for t in range(50):
+spans = []
+for t in range(300):
     a = dcd_hip.engine.random_actions(B, 0, 3, t, 7, "cuda")
     eng.step(a, 0, outb)
     torch.cuda.synchronize()
     s = st.cpu().numpy()
     acc.append(np.diff(s[:, :7], axis=1))
-    span = (s[:, 6].max() - s[:, 0].min())
+    span = (s[:, 1:7].max() - s[:, 0].min())
+    spans.append(span)
+spans = np.array(spans)
+print('grid span (first stamp to last stamp) per launch: median', np.median(spans[5:]), 'p90', np.percentile(spans[5:], 90), 'max', spans[5:].max(), 'at step', 5 + spans[5:].argmax())
+print('spans around step 249:', spans[245:255])
 acc = np.stack(acc[5:])
 med = np.median(acc, axis=(0, 1))
 for n, m in zip(names, med):
     print(f"{n:24s} {m:9.0f} cycles")
 print("per-block total median", np.median(acc.sum(-1)), "cycles; grid span last launch", span)
+tot = acc.sum(-1)                                   # [launch, block]
+worst = tot.argmax(1)
+print("slowest block per launch: mean total", tot.max(1).mean(), "cycles; phases (mean over launches):")
+for i, n in enumerate(names):
+    print(f"  {n:24s} {np.mean([acc[l, worst[l], i] for l in range(len(worst))]):9.0f}")
+print("percentiles of per-block total (50/90/99/100):", np.percentile(tot, [50, 90, 99, 100]))
+spans = []
+
