@@ -24,92 +24,119 @@ namespace {
 
 constexpr int PB = 256;          // threads per workgroup (4 waves)
 constexpr int FE = 8;            // envs per workgroup, features kernel
-constexpr int HE = 16;           // envs per workgroup, cell+heads kernel (4 per wave)
+constexpr int HE = 16;           // envs per workgroup, cell+heads kernel
+constexpr int CB = 512, CW = CB / 64, EW = HE / CW;   // its workgroup: 8 waves x 2 envs (two waves per SIMD hide each other's latency)
 constexpr int MAXV = 7, MAXF = 32, MAXH = 256, MAXA = 16;
 
 // ---- features ---------------------------------------------------------------------------------
+// VV/FF/EE/HH > 0: compile-time geometry (the registered student: V=5, F=16, E=5, H=256 -> K=405), so the
+// (env, k) index split is multiplications by constants; 0: runtime geometry.
+template <int VV, int FF, int EE, int HH>
 __global__ void __launch_bounds__(PB) policy_features_kernel(DcdStudentNet n, const float* __restrict__ image,
                                                              const float* __restrict__ direction, const float* __restrict__ hc,
-                                                             const float* __restrict__ masks, float* __restrict__ x, int B) {
+                                                             const float* __restrict__ masks, float* __restrict__ x, int KP, int B) {
   __shared__ float s_img[FE][3 * MAXV * MAXV];
   __shared__ float s_w[MAXF * 27 + MAXF];
+  __shared__ float s_emb[FE][16];
   const int tid = threadIdx.x, env0 = blockIdx.x * FE, ne = min(FE, B - env0);
-  const int V = n.V, O = V - 2, OO = O * O, CF = n.F * OO, K = CF + n.E + n.H, IMG = 3 * V * V;
+  const int V = VV ? VV : n.V, F = FF ? FF : n.F, E = VV ? EE : n.E, H = HH ? HH : n.H;
+  const int O = V - 2, OO = O * O, CF = F * OO, IMG = 3 * V * V;
+  // every global load of the workgroup is issued before the first wait: one memory round trip in all.
+  // (a) h * masks (common.py:151-153): ne*H values, HB per thread (H = 256 = PB: thread <-> hidden unit, i <-> env)
+  constexpr int HB = FE * MAXH / PB;
+  float hv[HB];
+#pragma unroll
+  for (int i = 0; i < HB; ++i) {
+    const int q = i * PB + tid, e = q / H, j = q - e * H;
+    hv[i] = q < ne * H ? hc[(size_t)(env0 + e) * 2 * H + j] * masks[env0 + e] : 0.f;
+  }
+  // (c) one_hot(dim, direction) @ W^T + b (:123-125) == column `direction` of W + b: a dependent gather, started now
+  if (tid < ne * E) {
+    const int e = tid / E, j = tid - e * E;
+    int d = (int)direction[env0 + e];
+    d = d < 0 ? 0 : (d >= n.D ? n.D - 1 : d);
+    s_emb[e][j] = n.embed_w[j * n.D + d] + n.embed_b[j];
+  }
   for (int q = tid; q < ne * IMG; q += PB) s_img[q / IMG][q % IMG] = image[(size_t)env0 * IMG + q];
-  for (int q = tid; q < n.F * 27; q += PB) s_w[q] = n.conv_w[q];
-  for (int q = tid; q < n.F; q += PB) s_w[MAXF * 27 + q] = n.conv_b[q];
+  for (int q = tid; q < F * 27; q += PB) s_w[q] = n.conv_w[q];
+  for (int q = tid; q < F; q += PB) s_w[MAXF * 27 + q] = n.conv_b[q];
+  __builtin_amdgcn_sched_barrier(0);                               // loads above stay batched ahead of the stores
+#pragma unroll
+  for (int i = 0; i < HB; ++i) {
+    const int q = i * PB + tid, e = q / H, j = q - e * H;
+    if (q < ne * H) x[(size_t)(env0 + e) * KP + CF + E + j] = hv[i];
+  }
   __syncthreads();
-  for (int q = tid; q < ne * K; q += PB) {
-    const int e = q / K, k = q - e * K, b = env0 + e;
-    float v;
-    if (k < CF) {                                                    // Conv2d 'valid' + Flatten + ReLU (:45-47)
-      const int f = k / OO, o = k - f * OO, oy = o / O, ox = o - oy * O;
-      const float* w = s_w + f * 27;
-      float acc = s_w[MAXF * 27 + f];
+  if (tid < ne * E) { const int e = tid / E, j = tid - e * E; x[(size_t)(env0 + e) * KP + CF + j] = s_emb[e][j]; }
+  // (b) Conv2d 'valid' + Flatten + ReLU (multigrid_models.py:45-47), image and weights in LDS
+  for (int q = tid; q < ne * CF; q += PB) {
+    const int e = q / CF, k = q - e * CF, f = k / OO, o = k - f * OO, oy = o / O, ox = o - oy * O;
+    const float* w = s_w + f * 27;
+    float acc = s_w[MAXF * 27 + f];
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) acc = fmaf(w[c * 9 + ky * 3 + kx], s_img[e][c * V * V + (oy + ky) * V + ox + kx], acc);
-      v = fmaxf(acc, 0.f);
-    } else if (k < CF + n.E) {                                       // one_hot(dim, direction) @ W^T + b (:123-125)
-      const int j = k - CF;
-      int d = (int)direction[b];
-      d = d < 0 ? 0 : (d >= n.D ? n.D - 1 : d);
-      v = n.embed_w[j * n.D + d] + n.embed_b[j];
-    } else {                                                         // h * masks (common.py:151-153)
-      const int j = k - CF - n.E;
-      v = hc[(size_t)b * 2 * n.H + j] * masks[b];
-    }
-    x[(size_t)b * K + k] = v;
+        for (int kx = 0; kx < 3; ++kx) acc = fmaf(w[c * 9 + ky * 3 + kx], s_img[e][c * V * V + (oy + ky) * V + ox + kx], acc);
+    x[(size_t)(env0 + e) * KP + k] = fmaxf(acc, 0.f);
   }
 }
 
 // ---- LSTM pointwise + heads + sampling ----------------------------------------------------------
+// rollout-time activations on the hardware exp/rcp (v_exp_f32 / v_rcp_f32, ~1 ulp each): |error| < 3e-7 on outputs in
+// [-1,1], inside the 3e-6 tolerance against the PyTorch module (tests/test_gpu_policy.py).  The TRAINING kernels
+// below keep the precise libm forms.
+__device__ __forceinline__ float fast_sigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) { const float a = fminf(fmaxf(v, -15.f), 15.f); return 1.f - 2.f * __frcp_rn(__expf(2.f * a) + 1.f); }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
 struct CellArgs {
   const float* gates; const float* hc_in; const float* masks; float* hc_out;
   float* value; int64_t* action; float* logp; float* log_dist; float* u_out;
-  uint32_t seed, counter; int64_t env_index_base; int32_t deterministic, B;
+  uint32_t seed, counter; const uint32_t* counter_base; int64_t env_index_base; int32_t deterministic, B;
 };
 
-// One wave per env at a time (4 envs per wave, 16 per workgroup).  Lane l owns hidden units l, l+64, l+128,
-// l+192 for the cell, then hidden unit l of the stacked [actor | critic] first layers, whose weights sit in
-// LDS transposed ([k][unit]: a wave reads 64 consecutive floats per k, h[k] is an LDS broadcast).
-template <int H>
-__global__ void __launch_bounds__(PB) policy_cell_heads_kernel(DcdStudentNet n, CellArgs a) {
-  extern __shared__ float smem[];
-  const int U = n.A1 + n.C1;                        // <= 64 stacked first-layer units
-  float* s_w1 = smem;                               // [H][64]
-  float* s_b1 = s_w1 + H * 64;                      // [64]
-  float* s_w2 = s_b1 + 64;                          // [MAXA][64]  row a: actor W2[a][:A1]; row NA: critic W2 in cols A1..
-  float* s_b2 = s_w2 + (MAXA + 1) * 64;             // [MAXA+1]
-  float* s_h = s_b2 + 32;                           // [4 waves][H]
-  float* s_t = s_h + 4 * H;                         // [4 waves][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int q = tid; q < H * 64; q += PB) {
-    const int k = q >> 6, u = q & 63;
-    s_w1[q] = u < n.A1 ? n.actor_w1[u * H + k] : (u < U ? n.critic_w1[(u - n.A1) * H + k] : 0.f);
-  }
-  if (tid < 64) s_b1[tid] = tid < n.A1 ? n.actor_b1[tid] : (tid < U ? n.critic_b1[tid - n.A1] : 0.f);
-  for (int q = tid; q < (MAXA + 1) * 64; q += PB) {
-    const int r = q >> 6, u = q & 63;
-    float w = 0.f;
+// Packed head weights (built by heads_pack_kernel whenever the optimiser stepped): w1t [H][64] = stacked
+// [actor | critic] first layers TRANSPOSED (a wave reads 64 consecutive floats per k), b1 [64],
+// w2 [16][68] (row a < NA: actor output a over units [0,A1); row NA: critic output over units [A1,U)), b2 [16].
+constexpr int W2P = 68;   // row pitch of w2: 68 mod 32 banks = 4, the 8 output lanes of an env hit distinct banks
+constexpr int PK_W1 = 0, PK_B1 = MAXH * 64, PK_W2 = PK_B1 + 64, PK_B2 = PK_W2 + MAXA * W2P, PK_FLOATS = PK_B2 + MAXA;
+static_assert(PK_FLOATS % 4 == 0, "packed heads are staged as float4");
+
+__global__ void __launch_bounds__(PB) heads_pack_kernel(DcdStudentNet n, float* __restrict__ pk) {
+  const int q = blockIdx.x * PB + threadIdx.x, H = n.H, U = n.A1 + n.C1;
+  if (q >= PK_FLOATS) return;
+  float w = 0.f;
+  if (q < PK_B1) { const int k = q >> 6, u = q & 63; w = u < n.A1 ? n.actor_w1[u * H + k] : (u < U ? n.critic_w1[(u - n.A1) * H + k] : 0.f); }
+  else if (q < PK_W2) { const int u = q - PK_B1; w = u < n.A1 ? n.actor_b1[u] : (u < U ? n.critic_b1[u - n.A1] : 0.f); }
+  else if (q < PK_B2) {
+    const int r = (q - PK_W2) / W2P, u = (q - PK_W2) % W2P;
     if (r < n.NA && u < n.A1) w = n.actor_w2[r * n.A1 + u];
     else if (r == n.NA && u >= n.A1 && u < U) w = n.critic_w2[u - n.A1];
-    s_w2[q] = w;
-  }
-  if (tid <= n.NA) s_b2[tid] = tid < n.NA ? n.actor_b2[tid] : n.critic_b2[0];
-  __syncthreads();
-  const int env0 = blockIdx.x * HE;
-  float* hb = s_h + wave * H;
-  float* tb = s_t + wave * 64;
-  for (int it = 0; it < HE / 4; ++it) {
-    const int b = env0 + it * 4 + wave;
-    const bool live = b < a.B;
-    if (live) {                                                       // nn.LSTM cell, gate order i,f,g,o
+  } else { const int r = q - PK_B2; w = r < n.NA ? n.actor_b2[r] : (r == n.NA ? n.critic_b2[0] : 0.f); }
+  pk[q] = w;
+}
+
+// Workgroup = CW waves x EW envs.  Cell: lane l owns hidden units l, l+64, l+128, l+192 of each of its wave's envs.
+// Heads layer 1: lane l = stacked unit l, the wave's envs advance together (one weight read feeds EW FMAs, their h
+// values come as one LDS broadcast).  Layer 2, log-softmax and sampling: 16 lanes per env.
+template <int H>
+__global__ void __launch_bounds__(CB) policy_cell_heads_kernel(DcdStudentNet n, const float* __restrict__ packed, CellArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_pk = smem;                               // PK_FLOATS
+  float* s_h = s_pk + PK_FLOATS;                    // [CW waves][H][EW envs]
+  float* s_t = s_h + CW * H * EW;                   // [CW waves][EW envs][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int q = tid; q < PK_FLOATS / 4; q += CB) reinterpret_cast<float4*>(s_pk)[q] = reinterpret_cast<const float4*>(packed)[q];
+  const uint32_t ctr = a.counter + (a.counter_base ? *a.counter_base : 0u);   // device-resident base: graph replays draw fresh numbers
+  float* hb = s_h + wave * H * EW;
+  float* tb = s_t + wave * EW * 64;
+  const int b0 = blockIdx.x * HE + wave * EW;
+#pragma unroll
+  for (int e = 0; e < EW; ++e) {                                       // nn.LSTM cell, gate order i,f,g,o
+    const int b = b0 + e;
+    if (b < a.B) {
       const float m = a.masks[b];
       const float* g = a.gates + (size_t)b * 4 * H;
       const float* ci = a.hc_in + (size_t)b * 2 * H + H;
@@ -118,54 +145,70 @@ __global__ void __launch_bounds__(PB) policy_cell_heads_kernel(DcdStudentNet n, 
       for (int q = 0; q < H / 64; ++q) {
         const int j = lane + 64 * q;
         const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
-        const float c = sigmoidf_(gf) * (ci[j] * m) + sigmoidf_(gi) * tanhf(gg);
-        const float h = sigmoidf_(go) * tanhf(c);
-        ho[j] = h; ho[H + j] = c; hb[j] = h;
+        const float c = fast_sigmoid(gf) * (ci[j] * m) + fast_sigmoid(gi) * fast_tanh(gg);
+        const float h = fast_sigmoid(go) * fast_tanh(c);
+        ho[j] = h; ho[H + j] = c; hb[j * EW + e] = h;
       }
+    } else {
+#pragma unroll
+      for (int q = 0; q < H / 64; ++q) hb[(lane + 64 * q) * EW + e] = 0.f;
     }
-    __syncthreads();
-    float acc = s_b1[lane];                                           // Linear(H -> 32) x2 + Tanh (common.py:215-224)
+  }
+  __syncthreads();
+  {                                                                   // Linear(H -> A1 | C1) + Tanh (common.py:215-224)
+    const float* w1 = s_pk + PK_W1;
+    const float bias = s_pk[PK_B1 + lane];
+    static_assert(EW == 2, "the layer-1 loop reads the wave's h values as one float2");
+    float a0 = bias, a1 = bias;
 #pragma unroll 8
-    for (int k = 0; k < H; ++k) acc = fmaf(s_w1[k * 64 + lane], hb[k], acc);
-    tb[lane] = tanhf(acc);
-    __syncthreads();
-    // lanes 0..NA-1: logits; lane NA: value
-    float out = 0.f;
-    if (lane <= n.NA) {
-      out = s_b2[lane];
-      for (int u = 0; u < U; ++u) out = fmaf(s_w2[lane * 64 + u], tb[u], out);
+    for (int k = 0; k < H; ++k) {
+      const float w = w1[k * 64 + lane];
+      const float2 h2 = *reinterpret_cast<const float2*>(hb + k * 2);
+      a0 = fmaf(w, h2.x, a0); a1 = fmaf(w, h2.y, a1);
     }
-    // log-softmax over lanes [0,NA) (Categorical(logits=...) normalises: logits - logsumexp)
-    const float lg = lane < n.NA ? out : -INFINITY;
-    float mx = lg;
+    tb[lane] = fast_tanh(a0); tb[64 + lane] = fast_tanh(a1);
+  }
+  __syncthreads();
+  const int e = lane >> 4, o = lane & 15, b = b0 + e, U = n.A1 + n.C1, grp = lane & ~15;
+  const bool live = e < EW && b < a.B;
+  float out = 0.f;                                                    // lanes o < NA: logits; o == NA: value
+  if (o <= n.NA && e < EW) {
+    out = s_pk[PK_B2 + o];
+    const float* w2 = s_pk + PK_W2 + o * W2P;
+    const float* t = tb + e * 64;
+    for (int u = 0; u < U; ++u) out = fmaf(w2[u], t[u], out);
+  }
+  // log-softmax over the NA lanes of this env's 16-lane group (Categorical(logits=...): logits - logsumexp)
+  const float lg = o < n.NA ? out : -INFINITY;
+  float mx = lg;
 #pragma unroll
-    for (int o = 1; o < MAXA; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float ex = lane < n.NA ? expf(lg - mx) : 0.f, sum = ex;
+  for (int s = 1; s < 16; s <<= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+  const float ex = o < n.NA ? expf(lg - mx) : 0.f;
+  float sum = ex;
 #pragma unroll
-    for (int o = 1; o < MAXA; o <<= 1) sum += __shfl_xor(sum, o);
-    const float lsm = lg - mx - logf(sum);
-    const float p = ex / sum;
-    // action: inverse CDF of one Philox uniform per (env, counter), or the first arg max
-    uint32_t r4[4];
-    dcd::philox4x32_10(a.counter, (uint32_t)(a.env_index_base + b), (uint32_t)((a.env_index_base + b) >> 32), 0x504F4C31u,
-                       a.seed, 0x41435421u, r4);
-    const float u01 = (float)(r4[0] >> 8) * (1.0f / 16777216.0f);
-    int act = 0; float cum = 0.f, best = -INFINITY; int arg = 0, chosen = -1;
-    for (int q = 0; q < n.NA; ++q) {
-      const float pq = __shfl(p, q), lq = __shfl(lg, q);
-      cum += pq;
-      if (chosen < 0 && u01 < cum) chosen = q;
-      if (lq > best) { best = lq; arg = q; }
-    }
-    if (chosen < 0) chosen = n.NA - 1;                                // cum rounded below u
-    act = a.deterministic ? arg : chosen;
-    const float lp = __shfl(lsm, act), val = __shfl(out, n.NA);
-    if (live) {
-      if (lane < n.NA) a.log_dist[(size_t)b * n.NA + lane] = lsm;
-      if (lane == 0) {
-        a.value[b] = val; a.action[b] = act; a.logp[b] = lp;
-        if (a.u_out) a.u_out[b] = u01;
-      }
+  for (int s = 1; s < 16; s <<= 1) sum += __shfl_xor(sum, s);
+  const float lsm = lg - mx - logf(sum);
+  const float p = ex / sum;
+  // action: inverse CDF of one Philox uniform per (env, counter), or the first arg max
+  uint32_t r4[4];
+  dcd::philox4x32_10(ctr, (uint32_t)(a.env_index_base + b), (uint32_t)((a.env_index_base + b) >> 32), 0x504F4C31u,
+                     a.seed, 0x41435421u, r4);
+  const float u01 = (float)(r4[0] >> 8) * (1.0f / 16777216.0f);
+  float cum = 0.f, best = -INFINITY; int arg = 0, chosen = -1;
+  for (int q = 0; q < n.NA; ++q) {
+    const float pq = __shfl(p, grp + q), lq = __shfl(lg, grp + q);
+    cum += pq;
+    if (chosen < 0 && u01 < cum) chosen = q;
+    if (lq > best) { best = lq; arg = q; }
+  }
+  if (chosen < 0) chosen = n.NA - 1;                                  // cum rounded below u
+  const int act = a.deterministic ? arg : chosen;
+  const float lp = __shfl(lsm, grp + act), val = __shfl(out, grp + n.NA);
+  if (live) {
+    if (o < n.NA) a.log_dist[(size_t)b * n.NA + o] = lsm;
+    if (o == 0) {
+      a.value[b] = val; a.action[b] = act; a.logp[b] = lp;
+      if (a.u_out) a.u_out[b] = u01;
     }
   }
 }
@@ -236,31 +279,45 @@ static int check_net(const DcdStudentNet* n) {
   if (n->H != MAXH) return dcd::fail("dcd_policy: hidden size %d unsupported (256)", n->H);
   if (n->A1 < 1 || n->C1 < 1 || n->A1 + n->C1 > 64) return dcd::fail("dcd_policy: head widths %d+%d exceed 64", n->A1, n->C1);
   if (n->NA < 1 || n->NA >= MAXA) return dcd::fail("dcd_policy: %d actions unsupported (<16)", n->NA);
-  if (n->E < 0 || n->D < 1) return dcd::fail("dcd_policy: bad scalar embedding E=%d D=%d", n->E, n->D);
+  if (n->E < 0 || n->E > 16 || n->D < 1) return dcd::fail("dcd_policy: bad scalar embedding E=%d D=%d", n->E, n->D);
   return 0;
 }
 
 int dcd_policy_input_width(const DcdStudentNet* n) { return n ? n->F * (n->V - 2) * (n->V - 2) + n->E + n->H : 0; }
 
 int dcd_policy_features(const DcdStudentNet* net, const float* image, const float* direction, const float* hc,
-                        const float* masks, float* x, int32_t B, void* stream) {
+                        const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream) {
   if (check_net(net)) return 1;
+  if (x_pitch < dcd_policy_input_width(net)) return dcd::fail("dcd_policy_features: x_pitch %d < K", x_pitch);
   if (!image || !direction || !hc || !masks || !x || B <= 0) return dcd::fail("dcd_policy_features: NULL pointer or B <= 0");
-  hipLaunchKernelGGL(policy_features_kernel, dim3((B + FE - 1) / FE), dim3(PB), 0, (hipStream_t)stream, *net, image, direction,
-                     hc, masks, x, B);
+  const dim3 grid((B + FE - 1) / FE), block(PB);
+  if (net->V == 5 && net->F == 16 && net->E == 5 && net->H == 256)
+    hipLaunchKernelGGL((policy_features_kernel<5, 16, 5, 256>), grid, block, 0, (hipStream_t)stream, *net, image, direction, hc, masks, x, x_pitch, B);
+  else
+    hipLaunchKernelGGL((policy_features_kernel<0, 0, 0, 0>), grid, block, 0, (hipStream_t)stream, *net, image, direction, hc, masks, x, x_pitch, B);
   if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_features: launch failed");
   return 0;
 }
 
-int dcd_policy_cell_heads(const DcdStudentNet* net, const float* gates, const float* hc_in, const float* masks, float* hc_out,
-                          float* value, int64_t* action, float* action_log_prob, float* action_log_dist, float* u_out,
-                          uint32_t seed, uint32_t counter, int64_t env_index_base, int32_t deterministic, int32_t B, void* stream) {
+int dcd_policy_packed_heads_floats(void) { return PK_FLOATS; }
+
+int dcd_policy_pack_heads(const DcdStudentNet* net, float* packed, void* stream) {
   if (check_net(net)) return 1;
-  if (!gates || !hc_in || !masks || !hc_out || !value || !action || !action_log_prob || !action_log_dist || B <= 0)
+  if (!packed) return dcd::fail("dcd_policy_pack_heads: NULL output");
+  hipLaunchKernelGGL(heads_pack_kernel, dim3((PK_FLOATS + PB - 1) / PB), dim3(PB), 0, (hipStream_t)stream, *net, packed);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_pack_heads: launch failed");
+  return 0;
+}
+
+int dcd_policy_cell_heads(const DcdStudentNet* net, const float* packed, const float* gates, const float* hc_in, const float* masks, float* hc_out,
+                          float* value, int64_t* action, float* action_log_prob, float* action_log_dist, float* u_out,
+                          uint32_t seed, uint32_t counter, const uint32_t* counter_base, int64_t env_index_base, int32_t deterministic, int32_t B, void* stream) {
+  if (check_net(net)) return 1;
+  if (!packed || !gates || !hc_in || !masks || !hc_out || !value || !action || !action_log_prob || !action_log_dist || B <= 0)
     return dcd::fail("dcd_policy_cell_heads: NULL pointer or B <= 0");
-  CellArgs a{gates, hc_in, masks, hc_out, value, action, action_log_prob, action_log_dist, u_out, seed, counter, env_index_base,
+  CellArgs a{gates, hc_in, masks, hc_out, value, action, action_log_prob, action_log_dist, u_out, seed, counter, counter_base, env_index_base,
              deterministic, B};
-  const size_t lds = sizeof(float) * (MAXH * 64 + 64 + (MAXA + 1) * 64 + 32 + 4 * MAXH + 4 * 64);
+  const size_t lds = sizeof(float) * (PK_FLOATS + CW * MAXH * EW + CW * EW * 64);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_cell_heads_kernel<MAXH>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -268,7 +325,7 @@ int dcd_policy_cell_heads(const DcdStudentNet* net, const float* gates, const fl
       return dcd::fail("dcd_policy_cell_heads: cannot reserve %zu bytes of LDS", lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(policy_cell_heads_kernel<MAXH>, dim3((B + HE - 1) / HE), dim3(PB), lds, (hipStream_t)stream, *net, a);
+  hipLaunchKernelGGL(policy_cell_heads_kernel<MAXH>, dim3((B + HE - 1) / HE), dim3(CB), lds, (hipStream_t)stream, *net, packed, a);
   if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_cell_heads: launch failed");
   return 0;
 }

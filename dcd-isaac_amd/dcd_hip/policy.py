@@ -31,7 +31,7 @@ class StudentActor:
     def __init__(self, net, num_envs, seed=0, env_index_base=0):
         self.net, self.B = net, int(num_envs)
         self.seed, self.env_index_base = int(seed) & 0xFFFFFFFF, int(env_index_base)
-        self.counter = 0
+        self.counter = 0                                            # immediate part of the Philox counter (step index)
         conv = net.image_conv[0]
         lstm = net.rnn.rnn
         self.H = lstm.hidden_size
@@ -46,8 +46,13 @@ class StudentActor:
                           H=self.H, A1=a1.out_features, C1=c1.out_features, NA=a2.out_features)
         self._lstm = lstm
         self.K = self._dims["F"] * (V - 2) ** 2 + self._dims["E"] + self.H
-        self.x = torch.empty((self.B, self.K), device=dev)
+        self.KP = (self.K + 31) // 32 * 32                             # K padded for the GEMM (405 -> 416): zero columns / rows
+        self.x = torch.zeros((self.B, self.KP), device=dev)
         self.gates = torch.empty((self.B, 4 * self.H), device=dev)
+        self.w_t = torch.zeros((self.KP, 4 * self.H), device=dev)     # persistent: captured HIP graphs keep pointing at them
+        self.bias = torch.empty((4 * self.H,), device=dev)
+        self.packed = torch.empty((lib().dcd_policy_packed_heads_floats(),), device=dev)   # head weights in the kernel's layout
+        self.counter_base = torch.zeros(1, dtype=torch.int32, device=dev)   # device part of the counter (rollouts so far x T)
         self._struct = None
         self._w_version = None
         self.refresh()
@@ -80,17 +85,18 @@ class StudentActor:
         return cls(net, num_envs, seed=seed, env_index_base=env_index_base)
 
     def refresh(self):
-        """Re-read parameter pointers and rebuild the stacked LSTM weight [4H, K-H | H] when the optimiser
-        has stepped (in-place updates keep pointers but change values, so the stacked copy is refreshed
-        whenever any LSTM parameter's version counter moved)."""
+        """Re-read parameter pointers and rebuild, IN PLACE, the two derived buffers — the stacked LSTM weight
+        [K, 4H] and the packed head weights — when the optimiser has stepped (in-place updates keep pointers
+        but move the parameters' version counters)."""
         l = self._lstm
         ver = tuple(p._version for p in (l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0)) + \
-            tuple(p.data_ptr() for p in self._params)
+            tuple((p.data_ptr(), p._version) for p in self._params)
         if ver == self._w_version:
             return
         with torch.no_grad():
-            self.w_t = torch.cat([l.weight_ih_l0, l.weight_hh_l0], dim=1).t().contiguous()        # [K, 4H]
-            self.bias = (l.bias_ih_l0 + l.bias_hh_l0).contiguous()
+            self.w_t[:self.K - self.H].copy_(l.weight_ih_l0.t())       # [K, 4H] = [W_ih | W_hh]^T, refreshed in place
+            self.w_t[self.K - self.H:self.K].copy_(l.weight_hh_l0.t())
+            torch.add(l.bias_ih_l0, l.bias_hh_l0, out=self.bias)
         s = StudentNet()
         for name, p in zip([f[0] for f in StudentNet._fields_[:12]], self._params):
             setattr(s, name, ptr(p.detach(), torch.float32, name=name).value)
@@ -98,6 +104,7 @@ class StudentActor:
             setattr(s, k, v)
         self._struct = s
         self._w_version = ver
+        check(lib().dcd_policy_pack_heads(C.byref(s), ptr(self.packed), stream_ptr()))
         if lib().dcd_policy_input_width(C.byref(s)) != self.K:
             raise DcdHipError("dcd_policy_input_width disagrees with the network's LSTM input size")
 
@@ -111,21 +118,29 @@ class StudentActor:
         L = lib()
         check(L.dcd_policy_features(C.byref(s), ptr(image, torch.float32, B * 3 * self._dims["V"] ** 2, "image"),
                                     ptr(direction, torch.float32, B, "direction"), ptr(hc_in, torch.float32, B * 2 * self.H, "hc_in"),
-                                    ptr(masks, torch.float32, B, "masks"), ptr(self.x), C.c_int32(B), stream_ptr()))
+                                    ptr(masks, torch.float32, B, "masks"), ptr(self.x), C.c_int32(self.KP), C.c_int32(B), stream_ptr()))
         torch.addmm(self.bias, self.x, self.w_t, out=self.gates)
-        check(L.dcd_policy_cell_heads(C.byref(s), ptr(self.gates), ptr(hc_in), ptr(masks), ptr(hc_out, torch.float32, B * 2 * self.H, "hc_out"),
+        check(L.dcd_policy_cell_heads(C.byref(s), ptr(self.packed), ptr(self.gates), ptr(hc_in), ptr(masks), ptr(hc_out, torch.float32, B * 2 * self.H, "hc_out"),
                                       ptr(value, torch.float32, B, "value"), ptr(action, torch.int64, B, "action"),
                                       ptr(log_prob, torch.float32, B, "log_prob"),
                                       ptr(log_dist, torch.float32, B * self._dims["NA"], "log_dist"),
                                       ptr(u_out, torch.float32, B, "u_out") if u_out is not None else None,
-                                      C.c_uint32(self.seed), C.c_uint32(self.counter & 0xFFFFFFFF), C.c_int64(self.env_index_base),
+                                      C.c_uint32(self.seed), C.c_uint32(self.counter & 0xFFFFFFFF),
+                                      C.c_void_p(self.counter_base.data_ptr()), C.c_int64(self.env_index_base),
                                       C.c_int32(int(deterministic)), C.c_int32(B), stream_ptr()))
         self.counter += 1
+
+    def begin_rollout(self, num_steps):
+        """Call once per rollout, OUTSIDE any graph capture: picks up optimiser steps and advances the device
+        counter base by the rollout length, so step t of this rollout draws with counter base + t."""
+        self.refresh()
+        self.counter_base.add_(int(num_steps))
 
     def act_storage(self, st, step, deterministic=False):
         """`agent.act(obs[step], h[step], masks[step])` + `storage.insert_policy(...)` (adversarial_runner.py:506-517,
         algos/storage.py:155-185) without leaving the device: writes value_preds[step], actions[step],
         action_log_probs[step], action_log_dist[step], recurrent_hidden_states[step+1]."""
+        self.counter = step
         self.act_into(st.obs["image"][step], st.obs["direction"][step], st.recurrent_hidden_states[step], st.masks[step],
                       st.recurrent_hidden_states[step + 1], st.value_preds[step], st.actions[step], st.action_log_probs[step],
                       st.action_log_dist[step], deterministic=deterministic)

@@ -114,13 +114,15 @@ class AdversarialRunner:
         B = args.num_processes
         self._done_buf = torch.zeros(B, dtype=torch.uint8, device=self.device)
         self._seeds_dev = torch.full((B, 1), -1, dtype=torch.int32, device=self.device)
-        # HIP graphs (opt-in, DCD_HIP_GRAPHS=1): a rollout (policy forward + sampling + env step + storage
-        # writes) captured in chunks of GRAPH_CHUNK steps and replayed — the inner loop is launch-bound (~40
-        # small kernels per step).  OFF by default: with the PyTorch nets inside, capture/instantiate on
-        # ROCm 7.2 took minutes at B=4096 (the engine-only graph of bench.py, ~1.1k kernel nodes, is fine).
-        # Replay rollouts that re-sample levels on the host per step always stay eager.
+        # HIP graphs.  DCD_HIP_GRAPHS=1 (default): student rollouts whose policy step runs on the fused HIP path
+        # (dcd_hip.policy: 4 kernel nodes + 1 GEMM node per step) are captured in chunks of GRAPH_CHUNK steps and
+        # replayed: 17.9 -> 15.5 ms per 256-step rollout at B = 4096.  =2 also captures rollouts whose policy runs
+        # as PyTorch modules (teacher, unsupported nets: ~45 nodes per step; capture took minutes on ROCm 7.2).
+        # =0: always eager.  Replay rollouts that re-sample levels on the host per step always stay eager.
         import os
-        self.use_hip_graphs = os.environ.get("DCD_HIP_GRAPHS", "0") == "1" and self.device.type == "cuda"
+        mode = os.environ.get("DCD_HIP_GRAPHS", "1")
+        self.use_hip_graphs = mode in ("1", "2") and self.device.type == "cuda"
+        self.graph_pytorch_nets = mode == "2"       # also capture rollouts whose policy runs as PyTorch modules
         self._graphs = {}
 
     # ---- bookkeeping ---------------------------------------------------------------------------
@@ -314,8 +316,11 @@ class AdversarialRunner:
             g.replay()
 
     def _teacher_rollout(self, agent, num_steps):
-        self._graphed(("teacher", id(agent), num_steps, bool(agent.actor_critic.random)), num_steps,
-                      lambda t0, t1: self._teacher_rollout_body(agent, t0, t1))
+        body = lambda t0, t1: self._teacher_rollout_body(agent, t0, t1)
+        if self.graph_pytorch_nets:
+            self._graphed(("teacher", id(agent), num_steps, bool(agent.actor_critic.random)), num_steps, body)
+        else:
+            body(0, num_steps)
         agent.storage.step = 0
         self.ued_venv.raise_errors()
 
@@ -367,8 +372,11 @@ class AdversarialRunner:
         if track_seeds:
             self._seeds_dev.copy_(torch.tensor(self.current_level_seeds, dtype=torch.int32).view(-1, 1))
         host_resampling = level_sampler is not None and level_replay
+        fused = self._fused_actor(agent) if self.is_discrete_actions else None
+        if fused is not None:
+            fused.begin_rollout(num_steps)
         body = lambda t0, t1: self._student_rollout_body(agent, num_steps, t0, t1, level_replay, level_sampler, rollout_info)
-        if host_resampling:
+        if host_resampling or (fused is None and not self.graph_pytorch_nets):
             body(0, num_steps)
         else:
             self._graphed(("student", id(agent), num_steps, track_seeds, bool(agent.actor_critic.random)), num_steps, body)
@@ -400,8 +408,6 @@ class AdversarialRunner:
         st.step = t0
         track_seeds = level_sampler is not None
         fused = self._fused_actor(agent) if self.is_discrete_actions else None
-        if fused is not None:
-            fused.refresh()
         for step in range(t0, t1):
             if fused is not None:
                 fused.act_storage(st, step)

@@ -317,22 +317,29 @@ typedef struct DcdStudentNet {
 int dcd_policy_input_width(const DcdStudentNet* net);
 /* First half of MultigridNetwork._forward_base (multigrid_models.py:109-139) and of the masked
  * single-step LSTM (models/common.py:149-153): x[b] = [relu(conv(image[b])) flattened CHW |
- * scalar_embed(one_hot(direction[b])) | h[b]*masks[b]], x: float[B,K].  image: float[B,3,V,V],
+ * scalar_embed(one_hot(direction[b])) | h[b]*masks[b]], x: float[B,x_pitch] (x_pitch >= K; columns [K,x_pitch) are
+ * left untouched: zero them once to pad K for the GEMM).  image: float[B,3,V,V],
  * direction: float[B], hc: float[B,2H] (h | c: RolloutStorage.recurrent_hidden_states[step]),
  * masks: float[B].  The caller then forms gates = x @ [W_ih | W_hh]^T + (b_ih + b_hh) (one GEMM). */
 int dcd_policy_features(const DcdStudentNet* net, const float* image, const float* direction, const float* hc,
-                        const float* masks, float* x, int32_t B, void* stream);
+                        const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream);
+/* Head weights re-laid out for the kernel below (stacked + transposed first layers, padded second layers):
+ * packed: float[dcd_policy_packed_heads_floats()]; call again whenever the optimiser has stepped. */
+int dcd_policy_packed_heads_floats(void);
+int dcd_policy_pack_heads(const DcdStudentNet* net, float* packed, void* stream);
 /* Rest of `act` (multigrid_models.py:141-167): LSTM cell on gates float[B,4H] (order i,f,g,o) with
  * c = hc_in[:,H:]*masks -> hc_out float[B,2H] (storage.recurrent_hidden_states[step+1]); actor / critic
  * heads; action_log_dist float[B,NA] = normalised logits (FixedCategorical.logits); action int64[B] sampled
- * by inverse CDF from one Philox4x32-10 uniform per env, key (seed,'ACT!'), counter (counter, global env
- * index) — or the first arg max when deterministic; action_log_prob float[B]; value float[B].
+ * by inverse CDF from one Philox4x32-10 uniform per env, key (seed,'ACT!'), counter (counter + *counter_base,
+ * global env index) — or the first arg max when deterministic (counter_base: optional device uint32[1], read
+ * at run time so that a replayed HIP graph draws fresh numbers); action_log_prob float[B]; value float[B].
  * u_out (optional, tests): the uniform used.  The reference samples with torch.multinomial on the global
  * torch RNG; any exact sampler of the same distribution is equivalent. */
-int dcd_policy_cell_heads(const DcdStudentNet* net, const float* gates, const float* hc_in, const float* masks,
+int dcd_policy_cell_heads(const DcdStudentNet* net, const float* packed, const float* gates, const float* hc_in,
+                          const float* masks,
                           float* hc_out, float* value, int64_t* action, float* action_log_prob,
                           float* action_log_dist, float* u_out, uint32_t seed, uint32_t counter,
-                          int64_t env_index_base, int32_t deterministic, int32_t B, void* stream);
+                          const uint32_t* counter_base, int64_t env_index_base, int32_t deterministic, int32_t B, void* stream);
 
 /* ---- masked LSTM sequence of the PPO update (models/common.py:157-207) ------------------ */
 /* The reference cuts the flattened (T*N) sequence wherever ANY env has mask 0 and re-masks the state at each

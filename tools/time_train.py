@@ -21,11 +21,14 @@ def sync(): torch.cuda.synchronize()
 # rollout only (no update): S_roll
 runner.eval(); runner.is_training = False
 runner._teacher_rollout(teacher, 27)
-for _ in range(1): runner._student_rollout(agent, 256, False, None, {})
+sync(); t = time.perf_counter()
+for _ in range(3): runner._student_rollout(agent, 256, False, None, {})
+sync(); print('3 warm-up rollouts (incl. graph capture if enabled) s:', time.perf_counter() - t)
 sync(); t = time.perf_counter()
 for _ in range(2): runner._student_rollout(agent, 256, False, None, {})
 sync(); dt = (time.perf_counter() - t) / 2
 print(json.dumps({"S_roll_steps_per_s": B * 256 / dt, "student_rollout_ms": dt * 1e3}))
+if os.environ.get("ROLLOUT_ONLY"): sys.exit(0)
 sync(); t = time.perf_counter(); runner._teacher_rollout(teacher, 27); sync(); print("teacher rollout ms", (time.perf_counter() - t) * 1e3)
 runner.train(); runner.is_training = True
 for j in range(2):
