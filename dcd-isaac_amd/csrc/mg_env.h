@@ -543,17 +543,20 @@ DCD_HD double step_one_agent(Env& e, const Params& p, int action, int step_count
 // out: V*V*3 bytes indexed [vx][vy][c].  Out-of-grid cells render as Wall() (grey) (:330-334);
 // the agent's own cell shows the carried object or empty (:1009-1013); other Agent objects seen in
 // the view have their dir rotated with the view (rotate_left :308-314).
+// one cell of that view as a packed code: (vx,vy) of the V x V window of an agent at (ax,ay) facing d
+DCD_HD uint8_t view_cell_code(DCD_REC uint8_t* rec, int S, int V, int ax, int ay, int d, int carrying, int vx, int vy) {
+  const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3), rx = -fy, ry = fx, h = V / 2;
+  const int wx = ax + fx * (V - 1 - vy) + rx * (vx - h), wy = ay + fy * (V - 1 - vy) + ry * (vx - h);
+  if (vx == h && vy == V - 1) return (uint8_t)carrying;
+  if (wx < 0 || wx >= S || wy < 0 || wy >= S) return C_WALL_GREY;
+  uint8_t c = rec[wy * ROW + wx];
+  if (is_agent(c)) c = (uint8_t)(C_AGENT0 + (((c - C_AGENT0) - (d + 1)) & 3));
+  return c;
+}
 DCD_HD void render_view(Env& e, const Params& p, DCD_REC uint8_t* out) {
-  const int V = p.V, S = p.S, d = e.adir;
-  const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3), rx = -fy, ry = fx;
-  const int ax = e.ax, ay = e.ay, h = V / 2;
+  const int V = p.V;
   for (int vx = 0; vx < V; ++vx) for (int vy = 0; vy < V; ++vy) {
-    const int wx = ax + fx * (V - 1 - vy) + rx * (vx - h), wy = ay + fy * (V - 1 - vy) + ry * (vx - h);
-    uint8_t c;
-    if (vx == h && vy == V - 1) c = (uint8_t)e.carrying;
-    else if (wx < 0 || wx >= S || wy < 0 || wy >= S) c = C_WALL_GREY;
-    else { c = e.cell(wx, wy); if (is_agent(c)) c = (uint8_t)(C_AGENT0 + (((c - C_AGENT0) - (d + 1)) & 3)); }
-    const uint32_t t = enc3(c);
+    const uint32_t t = enc3(view_cell_code(e.r, p.S, V, e.ax, e.ay, e.adir, e.carrying, vx, vy));
     DCD_REC uint8_t* o = out + (vx * V + vy) * 3;
     o[0] = (uint8_t)t; o[1] = (uint8_t)(t >> 8); o[2] = (uint8_t)(t >> 16);
   }
@@ -561,17 +564,21 @@ DCD_HD void render_view(Env& e, const Params& p, DCD_REC uint8_t* out) {
 
 struct StepResult { float reward; uint8_t done, info; float ep_ret; int32_t ep_len; bool have_term; };
 
-// worker.step_env ∘ TimeLimit.step ∘ MultiGridEnv.step ∘ VecMonitor.step_wait [∘ runner last-step rule].
-// term (V*V*3 bytes + 1 dir byte at term[V*V*3]) receives the pre-reset obs when have_term.
-DCD_HD StepResult env_step(Env& e, const Params& p, Metrics& m, bool& metrics_dirty, int64_t action64,
-                           int flags, DCD_REC uint8_t* term) {
-  StepResult r;
+// worker.step_env ∘ TimeLimit.step ∘ MultiGridEnv.step ∘ VecMonitor.step_wait [∘ runner last-step rule], in two halves
+// so that the caller can render the pre-reset observation between them (the kernels do it cooperatively across a
+// wave; a lane-serial render_view of 25 cells cost 30 us whenever a time limit fired):
+//   env_step_pre   step_one_agent + done / TimeLimit detection            -> StepPre (have_term: obs wanted NOW)
+//   env_step_post  auto-reset, VecMonitor, last-step rule                  -> StepResult
+struct StepPre { double reward; bool done, have_term; uint8_t info; };
+
+DCD_HD StepPre env_step_pre(Env& e, const Params& p, int64_t action64) {
+  StepPre s;
   const int step_count = e.step_count + 1;                                 // multigrid.py:948
   e.step_count = step_count;
   const int action = (action64 < 0 || action64 > 6) ? 7 : (int)action64;
   // will TimeLimit attach truncated_obs this step?  (then the respawn position is observable)
   const bool will_term = p.max_episode_steps > 0 && e.elapsed + 1 >= p.max_episode_steps;
-  const double reward = step_one_agent(e, p, action, step_count, will_term);
+  s.reward = step_one_agent(e, p, action, step_count, will_term);
   bool done = e.done >= 1;                                               // competitive, n_agents == 1
   if (DCD_RARE(step_count >= p.max_steps)) done = true;                   // :972-973
   uint8_t info = 0; bool have_term = false;
@@ -583,14 +590,20 @@ DCD_HD StepResult env_step(Env& e, const Params& p, Metrics& m, bool& metrics_di
       have_term = true; done = true;
     }
   }
-  if (DCD_RARE(have_term)) { render_view(e, p, term); term[p.V * p.V * 3] = (uint8_t)e.adir; }
+  s.done = done; s.info = info; s.have_term = have_term;
+  return s;
+}
+
+DCD_HD StepResult env_step_post(Env& e, const Params& p, Metrics& m, bool& metrics_dirty, int flags, const StepPre& s) {
+  StepResult r;
+  bool done = s.done; uint8_t info = s.info;
   if (DCD_RARE(done)) {                                                    // parallel_wrappers.py:27-37
     if (flags & DCD_STEP_RESET_RANDOM) { env_reset_random(e, p, m); metrics_dirty = true; }
     reset_agent(e);
     e.elapsed = 0;                                                         // time_limit.py:39-49
   }
   // VecMonitor.step_wait (vec_monitor.py:60-85): eprets(f32) += rews(f64) is an fp64 add rounded to f32
-  float epr = (float)((double)e.ep_ret + reward);
+  float epr = (float)((double)e.ep_ret + s.reward);
   int epl = e.ep_len + 1;
   r.ep_ret = 0.f; r.ep_len = 0;
   if (DCD_RARE(done)) { info |= DCD_INFO_EPISODE; r.ep_ret = epr; r.ep_len = epl; epr = 0.f; epl = 0; }
@@ -599,9 +612,18 @@ DCD_HD StepResult env_step(Env& e, const Params& p, Metrics& m, bool& metrics_di
     if (!done) info |= DCD_INFO_CLIFFHANGER | DCD_INFO_TRUNC_KEY | DCD_INFO_TRUNCATED;
     done = true;
   }
-  r.reward = (float)reward; r.done = done; r.info = info;
-  r.have_term = have_term && (info & DCD_INFO_EPISODE);                    // runner inserts only then (:539-549)
+  r.reward = (float)s.reward; r.done = done; r.info = info;
+  r.have_term = s.have_term && (info & DCD_INFO_EPISODE);                  // runner inserts only then (:539-549)
   return r;
+}
+
+// both halves with a lane-serial render between them (tests/hostsim, level kernels).
+// term (V*V*3 bytes + 1 dir byte at term[V*V*3]) receives the pre-reset obs when have_term.
+DCD_HD StepResult env_step(Env& e, const Params& p, Metrics& m, bool& metrics_dirty, int64_t action64,
+                           int flags, DCD_REC uint8_t* term) {
+  const StepPre s = env_step_pre(e, p, action64);
+  if (DCD_RARE(s.have_term)) { render_view(e, p, term); term[p.V * p.V * 3] = (uint8_t)e.adir; }
+  return env_step_post(e, p, m, metrics_dirty, flags, s);
 }
 
 }  // namespace dcd

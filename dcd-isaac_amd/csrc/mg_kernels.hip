@@ -201,7 +201,10 @@ struct StepRes { float reward, ep_ret; int ep_len; uint32_t flags; uint32_t doff
 //   duty wave A (tid NT+lane)  per-env scalar outputs (reward, done, info, episode stats, masks) -> global
 //   duty wave B (tid NT+64+lane) record write-back: 16-byte dynamic state + the <=2 cells changed (or the whole record)
 // so the logic wave's critical path holds no global stores at all.
-template <bool RANDOM, int EPB>
+// RR: the launch may auto-reset finished envs to RANDOM levels (DR without PLR).  A compile-time flag because that
+// path inlines reset_random + the BFS metrics: the other variant is a third of the code (instruction-cache misses
+// on cold paths were a visible part of the slowest workgroup's time).
+template <bool RANDOM, int EPB, bool RR>
 __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel(Params p, StepArgs a) {
   constexpr int NT = Threads<EPB>::value;
   __shared__ __attribute__((aligned(16))) uint8_t lds[EPB * LP];
@@ -227,11 +230,13 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
   STAMP(2);
 
   unsigned long long episodes = 0;
-  if (tid < n) {
-    Env e = make_env(as_lds(lds + tid * LP), seed);
+  if (tid < WAVE) {                                  // the logic wave: lane <-> env for lanes < n, all 64 lanes for rare cooperative work
+    const bool live = tid < n;
+    const int step_flags = RR ? a.flags : (a.flags & ~DCD_STEP_RESET_RANDOM);
+    Env e = make_env(as_lds(lds + (live ? tid : 0) * LP), seed);
     Metrics m = {0, 0, 0, 0}; bool mdirty = false;
-    if (DCD_RARE(a.flags & DCD_STEP_RESET_RANDOM)) m = a.met[env];
-    StepResult r;
+    if (RR && live && (step_flags & DCD_STEP_RESET_RANDOM)) m = a.met[env];
+    StepResult r = {};
     const int K = RANDOM ? a.K : 1;
     for (int k = 0; k < K; ++k) {
       int64_t act = act0;
@@ -240,19 +245,44 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
         philox4x32_10(a.t0 + k, 0, 0, 0, a.action_seed, (uint32_t)(a.env_index_base + env), o);
         act = (int64_t)mulhi32(o[0], 7u);
       }
-      const int fl = (RANDOM && k != K - 1) ? (a.flags & ~DCD_STEP_LAST) : a.flags;
-      r = env_step(e, p, m, mdirty, act, fl, as_lds(sterm + tid * OP));
-      if (RANDOM) episodes += (r.info & DCD_INFO_EPISODE) ? 1 : 0;
+      const int fl = (RANDOM && k != K - 1) ? (step_flags & ~DCD_STEP_LAST) : step_flags;
+      StepPre sp = {};
+      if (live) sp = env_step_pre(e, p, act);
+      // pre-reset observation of envs whose time limit fired (info['truncated_obs']): one view cell per lane
+      unsigned long long tm = __ballot(live && sp.have_term);
+      if (DCD_RARE(tm != 0)) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the owners' cell writes are visible to the wave
+        const int V = p.V, VV = V * V;
+        while (tm) {
+          const int src = __builtin_ctzll(tm); tm &= tm - 1;
+          const int ax = __shfl(e.ax, src), ay = __shfl(e.ay, src), ad = __shfl(e.adir, src), ca = __shfl(e.carrying, src);
+          auto rec = as_lds(lds + src * LP);
+          auto out = as_lds(sterm + src * OP);
+          if (tid < VV) {
+            const int vx = tid / V, vy = tid - vx * V;
+            const uint32_t t = enc3(view_cell_code(rec, p.S, V, ax, ay, ad, ca, vx, vy));
+            out[tid * 3] = (uint8_t)t; out[tid * 3 + 1] = (uint8_t)(t >> 8); out[tid * 3 + 2] = (uint8_t)(t >> 16);
+          }
+          if (tid == 0) out[VV * 3] = (uint8_t)ad;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
+      if (live) {
+        r = env_step_post(e, p, m, mdirty, fl, sp);
+        if (RANDOM) episodes += (r.info & DCD_INFO_EPISODE) ? 1 : 0;
+      }
     }
-    if (DCD_RARE(r.have_term)) { term_valid[tid] = 1; any_term = 1; }
-    e.store_dyn();                                   // LDS copy feeds the render and the write-back wave
-    StepRes sr;
-    sr.reward = r.reward; sr.ep_ret = r.ep_ret; sr.ep_len = r.ep_len;
-    sr.flags = (uint32_t)r.done | ((uint32_t)r.info << 8) | ((uint32_t)(e.full_dirty ? 1 : 0) << 16) | ((uint32_t)min(e.nd, 2) << 20);
-    sr.doff = (uint32_t)e.doff0 | ((uint32_t)e.doff1 << 16);
-    res[tid] = sr;
-    if (DCD_RARE(mdirty)) a.met[env] = m;
-    if (DCD_RARE(e.err)) raise(a.errs, e.err, env);
+    if (live) {
+      if (DCD_RARE(r.have_term)) { term_valid[tid] = 1; any_term = 1; }
+      e.store_dyn();                                 // LDS copy feeds the render and the write-back wave
+      StepRes sr;
+      sr.reward = r.reward; sr.ep_ret = r.ep_ret; sr.ep_len = r.ep_len;
+      sr.flags = (uint32_t)r.done | ((uint32_t)r.info << 8) | ((uint32_t)(e.full_dirty ? 1 : 0) << 16) | ((uint32_t)min(e.nd, 2) << 20);
+      sr.doff = (uint32_t)e.doff0 | ((uint32_t)e.doff1 << 16);
+      res[tid] = sr;
+      if (RR && DCD_RARE(mdirty)) a.met[env] = m;
+      if (DCD_RARE(e.err)) raise(a.errs, e.err, env);
+    }
     STAMP(3);
   }
   __syncthreads();
@@ -681,9 +711,12 @@ int dcd_mg_step(DcdMg* h, const int64_t* actions, int32_t flags, const DcdStepOu
   if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) { e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1]; h->ev_used += 2; }
   const int epb = step_epb(h->p.B);
   const dim3 grid((h->p.B + epb - 1) / epb);
-  if (epb == 16) hipExtLaunchKernelGGL((mg_step_kernel<false, 16>), grid, dim3(Threads<16>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
-  else if (epb == 32) hipExtLaunchKernelGGL((mg_step_kernel<false, 32>), grid, dim3(Threads<32>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
-  else hipExtLaunchKernelGGL((mg_step_kernel<false, 64>), grid, dim3(Threads<64>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, h->p, a);
+#define DCD_LAUNCH_STEP(EPB_, RR_) hipExtLaunchKernelGGL((mg_step_kernel<false, EPB_, RR_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, h->p, a)
+  const bool rr = (flags & DCD_STEP_RESET_RANDOM) != 0;
+  if (epb == 16) { if (rr) DCD_LAUNCH_STEP(16, true); else DCD_LAUNCH_STEP(16, false); }
+  else if (epb == 32) { if (rr) DCD_LAUNCH_STEP(32, true); else DCD_LAUNCH_STEP(32, false); }
+  else { if (rr) DCD_LAUNCH_STEP(64, true); else DCD_LAUNCH_STEP(64, false); }
+#undef DCD_LAUNCH_STEP
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -730,9 +763,12 @@ int dcd_mg_step_random(DcdMg* h, uint32_t action_seed, uint32_t t0, int32_t K, i
   if (out) a.out = *out;
   const int epb = step_epb(h->p.B);
   const dim3 grid((h->p.B + epb - 1) / epb);
-  if (epb == 16) hipLaunchKernelGGL((mg_step_kernel<true, 16>), grid, dim3(Threads<16>::value + 2 * WAVE), 0, (hipStream_t)stream, h->p, a);
-  else if (epb == 32) hipLaunchKernelGGL((mg_step_kernel<true, 32>), grid, dim3(Threads<32>::value + 2 * WAVE), 0, (hipStream_t)stream, h->p, a);
-  else hipLaunchKernelGGL((mg_step_kernel<true, 64>), grid, dim3(Threads<64>::value + 2 * WAVE), 0, (hipStream_t)stream, h->p, a);
+#define DCD_LAUNCH_STEP(EPB_, RR_) hipLaunchKernelGGL((mg_step_kernel<true, EPB_, RR_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, h->p, a)
+  const bool rr = (flags & DCD_STEP_RESET_RANDOM) != 0;
+  if (epb == 16) { if (rr) DCD_LAUNCH_STEP(16, true); else DCD_LAUNCH_STEP(16, false); }
+  else if (epb == 32) { if (rr) DCD_LAUNCH_STEP(32, true); else DCD_LAUNCH_STEP(32, false); }
+  else { if (rr) DCD_LAUNCH_STEP(64, true); else DCD_LAUNCH_STEP(64, false); }
+#undef DCD_LAUNCH_STEP
   HIP_OK(hipGetLastError());
   return 0;
 }

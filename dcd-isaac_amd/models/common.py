@@ -207,7 +207,7 @@ class RNN(nn.Module):
         N = h.size(0)
         T = x.size(0) // N
         xp = torch.addmm(r.bias_ih_l0 + r.bias_hh_l0, x, r.weight_ih_l0.t()).view(T, N, 4 * H)
-        if _fused_lstm_enabled():
+        if x.is_cuda and _fused_lstm_enabled():
             out, hT, cT = MaskedLSTMSequence.apply(xp, h, c, masks.view(T, N), r.weight_hh_l0)
             return out.view(T * N, H), (hT, cT)
         return self._lstm_cuda_unfused(xp, h, c, masks, T, N)

@@ -120,7 +120,7 @@ static int decode_obj(uint8_t t, uint8_t c, uint8_t s, Obj* out) {
 
 typedef struct {
   /* MultiGridEnv (multigrid.py:341-463) */
-  int W, H, V, max_steps;
+  int W, H, V, max_steps, see_through_walls;
   Obj grid[MAXG * MAXG];            /* cell (i,j) at j*W+i (Appendix A.1) */
   int has_pos, ax, ay, adir;        /* agent_pos[0] / agent_dir[0] */
   int done;
@@ -236,6 +236,36 @@ static void view_rotate_left(const Obj* in, Obj* out, int V) {           /* :300
     out[(V - 1 - i) * V + j] = v;            /* grid.set(j, grid.height-1-i, v) */
   }
 }
+/* WorldObj.see_behind (gym-minigrid 1.0.1): Wall False, Door only when open, every other object
+ * (and the multigrid Agent, which inherits the default) True. */
+static int see_behind(Obj o) {
+  if (!o.present) return 1;
+  if (o.type == DCD_OBJ_WALL) return 0;
+  if (o.type == DCD_OBJ_DOOR) return o.state == 0;
+  return 1;
+}
+/* Grid.process_vis (gym-minigrid 1.0.1; call site multigrid.py:1000-1002): rows bottom to top, a
+ * left-to-right then a right-to-left sweep per row; a visible cell one can see through lights its neighbour in
+ * the sweep direction, the cell above it and the cell above that neighbour.  (The reference then sets unseen
+ * cells to None; Grid.encode(vis_mask) writes zeros for them either way.) */
+static void process_vis(const Obj* g, uint8_t* mask, int V, int ax, int ay) {
+  for (int k = 0; k < V * V; ++k) mask[k] = 0;
+  mask[ay * V + ax] = 1;
+  for (int j = V - 1; j >= 0; --j) {
+    for (int i = 0; i < V - 1; ++i) {
+      if (!mask[j * V + i]) continue;
+      if (!see_behind(g[j * V + i])) continue;
+      mask[j * V + i + 1] = 1;
+      if (j > 0) { mask[(j - 1) * V + i + 1] = 1; mask[(j - 1) * V + i] = 1; }
+    }
+    for (int i = V - 1; i >= 1; --i) {
+      if (!mask[j * V + i]) continue;
+      if (!see_behind(g[j * V + i])) continue;
+      mask[j * V + i - 1] = 1;
+      if (j > 0) { mask[(j - 1) * V + i - 1] = 1; mask[(j - 1) * V + i] = 1; }
+    }
+  }
+}
 static void gen_obs(const Env* e, uint8_t* image /* [V][V][3] indexed [vx][vy][c] */, uint8_t* dir) {
   int V = e->V, top_x, top_y;
   switch (e->adir) {                                                      /* get_view_exts :749-782 */
@@ -248,10 +278,18 @@ static void gen_obs(const Env* e, uint8_t* image /* [V][V][3] indexed [vx][vy][c
   view_slice(e, top_x, top_y, a);
   Obj *cur = a, *nxt = b;
   for (int r = 0; r < e->adir + 1; ++r) { view_rotate_left(cur, nxt, V); Obj* t = cur; cur = nxt; nxt = t; }
-  /* see_through_walls=True: vis_mask all ones (:1003-1004) */
+  uint8_t mask[MAXV * MAXV];                                              /* vis_mask[i][j] at j*V+i */
+  if (e->see_through_walls) {
+    for (int k = 0; k < V * V; ++k) mask[k] = 1;                          /* :1003-1004 */
+  } else {
+    process_vis(cur, mask, V, V / 2, V - 1);                              /* :1000-1002 */
+  }
   cur[(V - 1) * V + V / 2] = e->carrying;                                 /* :1009-1013 */
-  for (int i = 0; i < V; ++i) for (int j = 0; j < V; ++j)                 /* Grid.encode: [i][j] */
-    encode_obj(cur[j * V + i], image + (i * V + j) * 3);
+  for (int i = 0; i < V; ++i) for (int j = 0; j < V; ++j) {               /* Grid.encode(vis_mask): [i][j] */
+    uint8_t* o = image + (i * V + j) * 3;
+    if (mask[j * V + i]) encode_obj(cur[j * V + i], o);
+    else { o[0] = 0; o[1] = 0; o[2] = 0; }                                /* masked-out cells stay zero ('unseen') */
+  }
   *dir = (uint8_t)e->adir;
 }
 
@@ -620,7 +658,7 @@ static void emit_adv_obs(const Env* e, int row, const DcdAdvObs* o, const uint8_
 
 OrcMg* orc_mg_create(const DcdMgConfig* cfg) {
   if (!cfg || cfg->size < 3 || cfg->size > MAXG || cfg->agent_view_size > MAXV ||
-      !(cfg->agent_view_size & 1) || cfg->random_z_dim > 52 || !cfg->see_through_walls) return NULL;
+      !(cfg->agent_view_size & 1) || cfg->random_z_dim > 52) return NULL;
   OrcMg* h = (OrcMg*)calloc(1, sizeof(OrcMg));
   h->cfg = *cfg;
   h->envs = (Env*)calloc((size_t)cfg->num_envs, sizeof(Env));
@@ -628,6 +666,7 @@ OrcMg* orc_mg_create(const DcdMgConfig* cfg) {
   for (int b = 0; b < cfg->num_envs; ++b) {
     Env* e = &h->envs[b];
     e->W = e->H = cfg->size; e->V = cfg->agent_view_size; e->max_steps = cfg->max_steps;
+    e->see_through_walls = cfg->see_through_walls != 0;
     e->n_clutter = cfg->n_clutter; e->resample_n_clutter = cfg->resample_n_clutter;
     e->adversary_max_steps = cfg->n_clutter + 2;                          /* :107 */
     e->choose_goal_last = cfg->choose_goal_last; e->random_z_dim = cfg->random_z_dim;

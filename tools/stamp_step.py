@@ -43,6 +43,8 @@ worst = tot.argmax(1)
 print("slowest block per launch: mean total", tot.max(1).mean(), "cycles; phases (mean over launches):")
 for i, n in enumerate(names):
     print(f"  {n:24s} {np.mean([acc[l, worst[l], i] for l in range(len(worst))]):9.0f}")
+wl = tot.max(1).argmax(); wb = tot[wl].argmax()
+print("worst launch: step", 5 + wl, "block", wb, "phases", dict(zip(names, acc[wl, wb].tolist())), "median phases of that launch", dict(zip(names, np.median(acc[wl], axis=0).tolist())))
 print("percentiles of per-block total (50/90/99/100):", np.percentile(tot, [50, 90, 99, 100]))
 spans = []
 
