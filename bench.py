@@ -365,7 +365,7 @@ def main():
                        "env_steps_per_pass_per_gpu": ps.steps_per_pass(),
                        "episode_records_last_pass": n_recs, "episodes_last_pass": episodes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "mg_step_kernel<false,16>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "mg_step_kernel<false,16,false>",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_us": kernel_s * 1e6,
                          "note": "B=4096 moves 1.76 MB per launch: latency-bound, see DESIGN.md; --sweep adds large-B"},
         }

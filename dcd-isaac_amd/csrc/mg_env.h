@@ -62,6 +62,7 @@ struct Params {
       random_z_dim, n_editor_actions, fixed_environment;
   float goal_noise;
   uint32_t engine_seed;
+  int32_t see_through_walls;   // 0: gen_obs_grid masks the view with Grid.process_vis (multigrid.py:1000-1002)
 };
 
 // ---------------------------------------------------------------- Philox4x32-10 (Salmon et al. SC'11)
@@ -209,28 +210,85 @@ DCD_HD void reset_metrics(Metrics& m, const Params& p) {           // adversaria
   m.shortest_path_length = (p.S - 2) * (p.S - 2) + 1;
 }
 
-// _gen_grid (adversarial.py:166-172)
+// _gen_grid (adversarial.py:166-172): border of grey walls, None inside.  Whole rows as four 32-bit words (the side
+// column byte at x = 15 is preserved); cells beyond S stay None.
 DCD_HD void gen_grid(Env& e, const Params& p) {
   const int S = p.S;
-  for (int y = 0; y < S; ++y)
-    for (int x = 0; x < S; ++x)
-      e.cell(x, y) = (x == 0 || y == 0 || x == S - 1 || y == S - 1) ? C_WALL_GREY : C_NONE;
+  for (int y = 0; y < 15; ++y) {
+    DCD_REC uint32_t* q = reinterpret_cast<DCD_REC uint32_t*>(e.r + y * ROW);
+    const uint32_t side = q[3] & 0xFF000000u;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (y < S) {
+      if (y == 0 || y == S - 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) if (4 * k + b < S) w[k] |= (uint32_t)C_WALL_GREY << (8 * b);
+        }
+      } else {
+        w[0] = C_WALL_GREY;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if ((S - 1) >> 2 == k) w[k] |= (uint32_t)C_WALL_GREY << (8 * ((S - 1) & 3));
+      }
+    }
+    q[0] = w[0]; q[1] = w[1]; q[2] = w[2]; q[3] = (w[3] & 0x00FFFFFFu) | side;
+  }
   e.full_dirty = true;
+}
+
+// bit x of the result: cell (x,y) is a wall (codes 1..6), x < S.  Byte-parallel range test: codes are < 0x80, so the
+// per-byte additions cannot carry into the neighbouring byte.
+DCD_HD uint32_t row_wall_mask(Env& e, int y, int S) {
+  const DCD_REC uint32_t* q = reinterpret_cast<const DCD_REC uint32_t*>(e.r + y * ROW);
+  uint32_t m = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t w = q[k];
+    const uint32_t z = ((w + 0x7F7F7F7Fu) & ~(w + 0x79797979u)) & 0x80808080u;     // byte >= 1 and byte < 7
+    m |= ((((z >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * k);
+  }
+  return m & ((1u << S) - 1u);
+}
+
+// bit x of the result: cell (x,y) is None, x < S.  One 16-byte row read + exact zero-byte detection per dword
+// (the side column byte at x = 15 and the padding beyond S are masked off).
+DCD_HD uint32_t row_free_mask(Env& e, int y, int S) {
+  uint32_t w[4];
+  const DCD_REC uint32_t* q = reinterpret_cast<const DCD_REC uint32_t*>(e.r + y * ROW);      // rows are 16-byte aligned
+  w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
+  uint32_t m = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t z = ~((((w[k] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w[k]) | 0x7F7F7F7Fu);      // 0x80 in every zero byte
+    m |= ((((z >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * k);                                // gather the 4 flags
+  }
+  return m & ((1u << S) - 1u);
 }
 
 // place_obj with top=None,size=None (multigrid.py:565-632): uniform over None cells != agent_pos,
 // drawn as the k-th such cell in row-major order.  code==C_NONE: position only (place_one_agent).
+// Two passes over the S row masks (count, then locate): ~30 LDS reads instead of 2 x S*S byte reads.
 DCD_HD bool place_uniform(Env& e, const Params& p, uint8_t code, int* px, int* py) {
   const int S = p.S;
   const int ex = e.has_pos() ? e.ax : -1, ey = e.ay;
   int n = 0;
-  for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x)
-    n += (e.cell(x, y) == C_NONE && !(x == ex && y == ey)) ? 1 : 0;
+  for (int y = 0; y < S; ++y) {
+    uint32_t m = row_free_mask(e, y, S);
+    if (y == ey && ex >= 0) m &= ~(1u << ex);
+    n += __builtin_popcount(m);
+  }
   if (n == 0) { e.err |= DCD_ERR_NO_FREE_CELL; return false; }
   int k = randint(e, p, n);
-  for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x) {
-    if (e.cell(x, y) != C_NONE || (x == ex && y == ey)) continue;
-    if (k-- == 0) { if (code != C_NONE) e.set_cell(x, y, code); *px = x; *py = y; return true; }
+  for (int y = 0; y < S; ++y) {
+    uint32_t m = row_free_mask(e, y, S);
+    if (y == ey && ex >= 0) m &= ~(1u << ex);
+    const int c = __builtin_popcount(m);
+    if (k >= c) { k -= c; continue; }
+    for (; k > 0; --k) m &= m - 1;                           // drop the k lowest free cells of this row
+    const int x = __builtin_ctz(m);
+    if (code != C_NONE) e.set_cell(x, y, code);
+    *px = x; *py = y;
+    return true;
   }
   return false;
 }
@@ -269,7 +327,11 @@ DCD_HD void compute_metrics(Env& e, const Params& p, Metrics& m) {
 #pragma unroll
   for (int y = 0; y < 13; ++y) {
     uint16_t f = 0;
-    if (y < I) for (int x = 0; x < I; ++x) { bool w = is_wall(e.cell(x + 1, y + 1)); nw += w; f |= (uint16_t)((w ? 0 : 1) << x); }
+    if (y < I) {                                                   // interior row y+1: columns 1..I
+      const uint32_t w = (row_wall_mask(e, y + 1, p.S) >> 1) & ((1u << I) - 1u);
+      nw += __builtin_popcount(w);
+      f = (uint16_t)(~w & ((1u << I) - 1u));
+    }
     fr[y] = f; rc[y] = 0;
   }
   m.n_clutter_placed = nw;
@@ -553,10 +615,44 @@ DCD_HD uint8_t view_cell_code(DCD_REC uint8_t* rec, int S, int V, int ax, int ay
   if (is_agent(c)) c = (uint8_t)(C_AGENT0 + (((c - C_AGENT0) - (d + 1)) & 3));
   return c;
 }
+// WorldObj.see_behind (gym-minigrid 1.0.1): Wall no, Door only when open, everything else (None, the
+// multigrid Agent) yes.
+DCD_HD bool see_behind(uint8_t c) { return !(is_wall(c) || (is_door(c) && ((c - C_DOOR0) % 3) != 0)); }
+// Grid.process_vis (gym-minigrid 1.0.1) on bit boards, bit vx*V+vy: `transparent` marks the view cells
+// one can see through, the result marks the visible ones.  Rows from the agent's (vy = V-1) upwards; per row a
+// left-to-right then a right-to-left sweep; a visible see-through cell lights its neighbour in the sweep direction,
+// the cell above itself and the cell above that neighbour.
+DCD_HD uint64_t process_vis_mask(uint64_t transparent, int V) {
+  uint64_t m = 1ull << ((V / 2) * V + V - 1);
+  for (int vy = V - 1; vy >= 0; --vy) {
+    for (int vx = 0; vx < V - 1; ++vx) {
+      const uint64_t b = 1ull << (vx * V + vy);
+      if (!(m & transparent & b)) continue;
+      m |= b << V;                                             // (vx+1, vy)
+      if (vy > 0) m |= (b << V) >> 1 | b >> 1;                 // (vx+1, vy-1), (vx, vy-1)
+    }
+    for (int vx = V - 1; vx >= 1; --vx) {
+      const uint64_t b = 1ull << (vx * V + vy);
+      if (!(m & transparent & b)) continue;
+      m |= b >> V;                                             // (vx-1, vy)
+      if (vy > 0) m |= (b >> V) >> 1 | b >> 1;
+    }
+  }
+  return m;
+}
 DCD_HD void render_view(Env& e, const Params& p, DCD_REC uint8_t* out) {
-  const int V = p.V;
+  const int V = p.V, h = V / 2;
+  uint64_t vis = ~0ull;
+  if (!p.see_through_walls) {                                  // the agent's own cell holds the Agent object here: see-through
+    uint64_t tr = 0;
+    for (int vx = 0; vx < V; ++vx) for (int vy = 0; vy < V; ++vy)
+      if ((vx == h && vy == V - 1) || see_behind(view_cell_code(e.r, p.S, V, e.ax, e.ay, e.adir, e.carrying, vx, vy)))
+        tr |= 1ull << (vx * V + vy);
+    vis = process_vis_mask(tr, V);
+  }
   for (int vx = 0; vx < V; ++vx) for (int vy = 0; vy < V; ++vy) {
-    const uint32_t t = enc3(view_cell_code(e.r, p.S, V, e.ax, e.ay, e.adir, e.carrying, vx, vy));
+    uint32_t t = enc3(view_cell_code(e.r, p.S, V, e.ax, e.ay, e.adir, e.carrying, vx, vy));
+    if (!((vis >> (vx * V + vy)) & 1)) t = 0;                   // Grid.encode(vis_mask): unseen cells stay (0,0,0)
     DCD_REC uint8_t* o = out + (vx * V + vy) * 3;
     o[0] = (uint8_t)t; o[1] = (uint8_t)(t >> 8); o[2] = (uint8_t)(t >> 16);
   }

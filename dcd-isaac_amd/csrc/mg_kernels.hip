@@ -88,9 +88,12 @@ __device__ __forceinline__ void stage_out(const uint8_t* lds, uint8_t* __restric
 // multigrid.py:1080-1093, packed code from the LDS record, channel values from the code LUTs, stored
 // as fp32 CHW (/10) and/or u8 [vx][vy][c].  Consecutive threads hit consecutive view cells of the same
 // env, so each channel's store is a run of contiguous floats.  Semantics == dcd::render_view.
+// Opaque walls (see_through == 0): the TPE threads of an env sit in one wave, so the env's see-through bit board
+// is a slice of a wave ballot; every thread then runs Grid.process_vis on it (dcd::process_vis_mask) and drops
+// its cell if unseen — no LDS, no barrier.
 template <int V, int ROWS, int NT>
 __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
-                                            int n, int S, int tid) {
+                                            int n, int S, int tid, int see_through) {
   // TPE threads per env (power of two >= V*V): env = slot >> log2(TPE), view cell = slot & (TPE-1) — shifts
   // and masks instead of divisions; all offsets are 32-bit from per-workgroup base pointers.
   constexpr int VV = V * V, H = V / 2, TPE = VV <= 16 ? 16 : (VV <= 32 ? 32 : 64), ITERS = (ROWS * TPE + NT - 1) / NT;
@@ -112,6 +115,17 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
         if (oob && !own) c = C_WALL_GREY;
         else if (!own && c >= C_AGENT0 && c < C_DOOR0) c = C_AGENT0 + (((c - C_AGENT0) - (d + 1)) & 3);
         code[i] = (ax == NOPOS) ? 64 : c;                      // 64: no agent placed yet -> zero observation
+      }
+    }
+    if (DCD_RARE(!see_through)) {
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+        const int q = i * NT + tid, ci = q & (TPE - 1), vx = ci / V, vy = ci - vx * V;
+        const bool tr = code[i] >= 0 && code[i] != 64 && ((vx == H && vy == V - 1) || see_behind((uint8_t)code[i]));
+        const unsigned long long bal = __ballot(tr);
+        const unsigned long long mine = TPE == 64 ? bal : ((bal >> ((tid & 63) & ~(TPE - 1))) & ((1ull << (TPE & 63)) - 1ull));
+        const unsigned long long vis = process_vis_mask(mine, V);
+        if (code[i] >= 0 && !((vis >> ci) & 1)) code[i] = 64;
       }
     }
     __builtin_amdgcn_sched_barrier(0);                       // keep the gathers batched ahead of the LUT/store phase
@@ -142,10 +156,10 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
 }
 template <int ROWS, int NT>
 __device__ __forceinline__ void render_emit_v(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
-                                              int n, int S, int V, int tid) {
-  if (V == 5) render_emit<5, ROWS, NT>(lds, lut, o, out_row0, n, S, tid);
-  else if (V == 7) render_emit<7, ROWS, NT>(lds, lut, o, out_row0, n, S, tid);
-  else render_emit<3, ROWS, NT>(lds, lut, o, out_row0, n, S, tid);
+                                              int n, const Params& p, int tid) {
+  if (p.V == 5) render_emit<5, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls);
+  else if (p.V == 7) render_emit<7, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls);
+  else render_emit<3, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls);
 }
 
 // ---- emission of per-lane staged observations (terminal obs: rare) ---------------------------
@@ -258,9 +272,13 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
           const int ax = __shfl(e.ax, src), ay = __shfl(e.ay, src), ad = __shfl(e.adir, src), ca = __shfl(e.carrying, src);
           auto rec = as_lds(lds + src * LP);
           auto out = as_lds(sterm + src * OP);
+          const int vx = tid / V, vy = tid - vx * V;
+          const uint8_t cc = tid < VV ? view_cell_code(rec, p.S, V, ax, ay, ad, ca, vx, vy) : C_WALL_GREY;
+          unsigned long long vis = ~0ull;
+          if (!p.see_through_walls)
+            vis = process_vis_mask(__ballot(tid < VV && ((vx == V / 2 && vy == V - 1) || see_behind(cc))), V);
           if (tid < VV) {
-            const int vx = tid / V, vy = tid - vx * V;
-            const uint32_t t = enc3(view_cell_code(rec, p.S, V, ax, ay, ad, ca, vx, vy));
+            const uint32_t t = ((vis >> tid) & 1) ? enc3(cc) : 0u;
             out[tid * 3] = (uint8_t)t; out[tid * 3 + 1] = (uint8_t)(t >> 8); out[tid * 3 + 2] = (uint8_t)(t >> 16);
           }
           if (tid == 0) out[VV * 3] = (uint8_t)ad;
@@ -288,7 +306,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
   __syncthreads();
   STAMP(4);
   if (tid < NT) {
-    render_emit_v<EPB, NT>(lds, lut, a.out.obs, (size_t)env0, n, p.S, p.V, tid);     // post-auto-reset observation
+    render_emit_v<EPB, NT>(lds, lut, a.out.obs, (size_t)env0, n, p, tid);     // post-auto-reset observation
     STAMP(5);
     if (any_term) emit_staged<NT>(sterm, lut, a.out.term_obs, (size_t)env0, n, p.V, tid, term_valid);
     STAMP(6);
@@ -461,7 +479,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(Params p,
     if (S == 15) emit_grid<15, NT>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
     else emit_grid<0, NT>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
   } else {
-    render_emit_v<EPB, NT>(lds, lut, a.stu, (size_t)row0, n, S, p.V, tid);
+    render_emit_v<EPB, NT>(lds, lut, a.stu, (size_t)row0, n, p, tid);
   }
 }
 
@@ -589,7 +607,6 @@ int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out) {
   if (cfg->size < 3 || cfg->size > DCD_MAX_GRID) return dcd::fail("size %d outside [3,%d]", cfg->size, DCD_MAX_GRID);
   if (cfg->agent_view_size < 3 || cfg->agent_view_size > DCD_MAX_VIEW || !(cfg->agent_view_size & 1))
     return dcd::fail("agent_view_size %d must be odd in [3,%d]", cfg->agent_view_size, DCD_MAX_VIEW);
-  if (!cfg->see_through_walls) return dcd::fail("see_through_walls=False (process_vis) is not supported");
   if (cfg->random_z_dim < 0 || cfg->random_z_dim > 52) return dcd::fail("random_z_dim %d outside [0,52]", cfg->random_z_dim);
   if (cfg->editor_actions < 0 || cfg->editor_actions > 2) return dcd::fail("editor_actions must be 0..2");
   if (cfg->n_clutter < 0 || cfg->n_clutter + 2 > 255) return dcd::fail("n_clutter %d out of range", cfg->n_clutter);
@@ -604,6 +621,7 @@ int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out) {
   p.resample_n_clutter = cfg->resample_n_clutter; p.choose_goal_last = cfg->choose_goal_last;
   p.random_z_dim = cfg->random_z_dim; p.n_editor_actions = NEDIT[cfg->editor_actions];
   p.fixed_environment = cfg->fixed_environment; p.goal_noise = cfg->goal_noise; p.engine_seed = cfg->engine_seed;
+  p.see_through_walls = cfg->see_through_walls != 0;
   const size_t B = (size_t)p.B;
   if (hipMalloc(&h->rec, B * REC_BYTES) != hipSuccess || hipMalloc(&h->seed, B * 4) != hipSuccess ||
       hipMalloc(&h->met, B * sizeof(Metrics)) != hipSuccess || hipMalloc(&h->errs, 8) != hipSuccess) {

@@ -88,7 +88,7 @@ typedef struct DcdMgConfig {
   int32_t  n_clutter;
   int32_t  resample_n_clutter;
   int32_t  choose_goal_last;
-  int32_t  see_through_walls;   /* must be 1 this round (opaque ids: unsupported) */
+  int32_t  see_through_walls;   /* 0: views masked by Grid.process_vis (the ...OpaqueWalls... ids, multigrid.py:1000-1002) */
   int32_t  random_z_dim;        /* <= 64 */
   int32_t  editor_actions;      /* 0 walls_none, 1 walls_none_goal, 2 walls_none_agent_goal */
   int32_t  fixed_environment;

@@ -22,6 +22,11 @@ CONFIGS = [
     (4, dict(choose_goal_last=0, goal_noise=0.3, n_clutter=50, editor_actions=1), True, 63),
     (5, dict(size=10, n_clutter=30, max_steps=200, max_episode_steps=200, agent_view_size=7, editor_actions=0), True, 1),
     (6, dict(n_clutter=25, choose_goal_last=1, agent_view_size=3, fixed_environment=1), False, 200),
+    # opaque walls (Grid.process_vis; MultiGrid-GoalLast[FewerBlocks]OpaqueWallsAdversarial-v0, adversarial.py:609-612,655-658)
+    (7, dict(n_clutter=25, choose_goal_last=1, see_through_walls=0), False, 130),
+    (8, dict(n_clutter=50, choose_goal_last=1, see_through_walls=0, max_episode_steps=40), True, 67),
+    (9, dict(size=10, n_clutter=30, max_steps=200, max_episode_steps=60, agent_view_size=7, see_through_walls=0), True, 33),
+    (10, dict(size=6, n_clutter=7, max_steps=50, max_episode_steps=50, agent_view_size=3, see_through_walls=0), False, 100),
 ]
 
 

@@ -163,3 +163,17 @@ def test_device_rollout_equals_reference_host_loop():
     assert int((sa.ep_info & 1).sum()) == eps
     assert torch.equal(va.get_encodings_device(), vb.get_encodings_device())
     va.close(); vb.close()
+
+
+def test_opaque_walls_env_trains():
+    """MultiGrid-GoalLastFewerBlocksOpaqueWallsAdversarial-v0 (adversarial.py:655-658): views masked by
+    Grid.process_vis — unseen cells are all-zero triples, which never occur with see-through walls."""
+    args = make_args(ued_algo="paired", env_name="MultiGrid-GoalLastFewerBlocksOpaqueWallsAdversarial-v0")
+    runner, venv = build(args)
+    stats = runner.run()
+    img = runner.agents["agent"].storage.obs["image"]                  # [T+1,B,3,5,5] = encoding / 10
+    unseen = (img == 0).all(dim=2)
+    assert unseen.any() and not unseen.all()
+    assert not unseen[..., 2, 4].any()                               # the agent's own cell is always visible
+    assert np.isfinite(stats["agent_value_loss"])
+    venv.close()

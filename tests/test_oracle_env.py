@@ -148,3 +148,61 @@ def test_errors_are_latched():
     enc[1, 3, 3] = (11, 0, 0)
     m.reset_to_encoding(enc)
     assert m.poll_errors() == (8, 1)
+
+
+# ---- opaque walls: Grid.process_vis known answers (hand-derived from the algorithm text) ----------
+def _opaque_view(cls, walls, V=5):
+    """15x15 walled grid, agent at (7,7), goal at (1,1), `walls` extra wall cells; returns the type channel of the
+    view as rows vy = 0 (far) .. V-1 (agent's row), columns vx, for whatever start direction was drawn, plus dir."""
+    o = cls(num_envs=1, size=15, agent_view_size=V, see_through_walls=0, n_clutter=25, choose_goal_last=1)
+    enc = np.zeros((1, 15, 15, 3), np.uint8)
+    enc[..., 0] = 1
+    for k in range(15):
+        for (x, y) in ((0, k), (14, k), (k, 0), (k, 14)):
+            enc[0, x, y] = (2, 5, 0)
+    for (x, y) in walls:
+        enc[0, x, y] = (2, 5, 0)
+    enc[0, 7, 7] = (10, 0, 0)
+    enc[0, 1, 1] = (8, 1, 0)
+    o.reset()
+    r = o.reset_to_encoding(enc)
+    return r["image_u8"][0][..., 0].T, int(r["dir_u8"][0])
+
+
+def _engines():
+    from tests.hostsim import sim
+    return [orc.OracleMg, sim.HostSimMg]
+
+
+@pytest.mark.parametrize("cls", _engines())
+def test_process_vis_open_field_sees_everything(cls):
+    img, _ = _opaque_view(cls, [])
+    assert (img == 1).all()                                          # empty cells everywhere, none masked to 0
+
+
+@pytest.mark.parametrize("cls", _engines())
+def test_process_vis_walls_on_four_sides_leak_diagonally(cls):
+    """Walls N/E/S/W of the agent (symmetric, so the random start direction does not matter).  Row of the agent:
+    the side walls are lit but block, so the corners stay dark; the row above is lit through the agent's own cell
+    and its two diagonal neighbours are empty, which re-lights everything further up (gym-minigrid's diagonal leak)."""
+    img, _ = _opaque_view(cls, [(8, 7), (6, 7), (7, 8), (7, 6)])
+    expect = np.array([[1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 2, 1, 1], [0, 2, 1, 2, 0]])
+    assert np.array_equal(img, expect)
+
+
+@pytest.mark.parametrize("cls", _engines())
+def test_process_vis_fully_enclosed_agent_sees_only_the_ring(cls):
+    ring = [(x, y) for x in (6, 7, 8) for y in (6, 7, 8) if (x, y) != (7, 7)]
+    img, _ = _opaque_view(cls, ring)
+    expect = np.array([[0, 0, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0], [0, 2, 2, 2, 0], [0, 2, 1, 2, 0]])
+    assert np.array_equal(img, expect)
+
+
+@pytest.mark.parametrize("cls", _engines())
+def test_process_vis_wall_line_ahead_hides_what_is_behind(cls):
+    """A full line of walls two cells ahead in every direction (a 5x5 box around the agent): the row of the box
+    is visible, nothing beyond it."""
+    box = [(x, y) for x in range(5, 10) for y in range(5, 10) if x in (5, 9) or y in (5, 9)]
+    img, _ = _opaque_view(cls, box)
+    expect = np.array([[0, 0, 0, 0, 0], [0, 0, 0, 0, 0], [2, 2, 2, 2, 2], [2, 1, 1, 1, 2], [2, 1, 1, 1, 2]])
+    assert np.array_equal(img, expect)

@@ -22,7 +22,7 @@ def mean_counter(d, counter, kernel="mg_step_kernel<false"):
 
 fetch_kb, nf = mean_counter(sys.argv[1], "FETCH_SIZE")
 write_kb, nw = mean_counter(sys.argv[2], "WRITE_SIZE")
-out = {"kernel": "mg_step_kernel<false,16>", "launches_sampled": [nf, nw], "FETCH_SIZE_KB_raw": fetch_kb,
+out = {"kernel": "mg_step_kernel<false,16,false>", "launches_sampled": [nf, nw], "FETCH_SIZE_KB_raw": fetch_kb,
        "WRITE_SIZE_KB_raw": write_kb,
        "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024 if fetch_kb is not None and write_kb is not None else None,
        "correction": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE as reported (4-B/lane stores: width uncalibrated)",
