@@ -29,6 +29,8 @@ def build(args):
     agent = make_agent("agent", venv, args, DEV)
     adversary_agent = make_agent("adversary_agent", venv, args, DEV) if args.ued_algo in ("paired", "flexible_paired") else None
     adversary_env = make_agent("adversary_env", venv, args, DEV)
+    if args.ued_algo == "domain_randomization" and args.use_plr and not args.use_reset_random_dr:
+        adversary_env.random()                                         # train.py:84-86
     plr_args = make_plr_args(args, venv.observation_space, venv.action_space) if args.use_plr else None
     runner = AdversarialRunner(args=args, venv=venv, agent=agent, ued_venv=ued_venv, adversary_agent=adversary_agent,
                                adversary_env=adversary_env, train=True, plr_args=plr_args, device=DEV)
@@ -176,4 +178,35 @@ def test_opaque_walls_env_trains():
     assert unseen.any() and not unseen.all()
     assert not unseen[..., 2, 4].any()                               # the agent's own cell is always visible
     assert np.isfinite(stats["agent_value_loss"])
+    venv.close()
+
+
+def _shipped_configs():
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mg_train_configs.json")
+    return sorted(json.load(open(path)).items())
+
+
+@pytest.mark.parametrize("name,flags", _shipped_configs())
+def test_every_shipped_multigrid_config_trains(name, flags):
+    """Drop-in check over the reference's own MultiGrid training configurations (train_scripts/grid_configs/
+    minigrid/*/*.json -> `python -m train --k=v ...`, make_cmd.py:30-45): every flag parses with our
+    arguments.parser and three updates of the configured algorithm (DR, minimax, PAIRED, PLR, REPAIRED,
+    robust PLR, ACCEL) run on the GPU path.  Shrunk only in scale: 48-step rollouts, a 64-level replay buffer."""
+    from arguments import parser
+    argv = [f"--{k}={v}" for k, v in flags.items()]
+    args = parser.parse_args(argv)
+    for k, v in flags.items():                                      # what was parsed is what the config says
+        got = getattr(args, k)
+        assert (got == v) or (isinstance(v, float) and abs(got - v) < 1e-12) or (k == "log_dir"), (k, got, v)
+    args.num_steps, args.seed = 48, 5
+    if args.use_plr:
+        args.level_replay_seed_buffer_size = 64
+    runner, venv = build(args)
+    np.random.seed(1)
+    stats = [runner.run() for _ in range(3)][-1]
+    assert stats["steps"] == (3 + runner.total_num_edits) * args.num_processes * 48
+    assert np.isfinite(stats["agent_value_loss"]) and stats["total_episodes"] > 0
+    if args.use_plr and args.level_replay_prob > 0:
+        assert len(runner.level_store) > 0
     venv.close()
