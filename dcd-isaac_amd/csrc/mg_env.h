@@ -39,17 +39,38 @@
 // vmcnt and would wait for outstanding global stores).  Host builds (tests/hostsim) use plain pointers.
 // rare-path hints: the hot step falls through; resets, respawns and error paths are laid out cold
 #define DCD_RARE(x) __builtin_expect(!!(x), 0)
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DCD_REC_GENERIC)
 #define DCD_REC __attribute__((address_space(3)))
 #else
-#define DCD_REC
+#define DCD_REC                /* host builds, and the large-grid kernels (mg_big.hip) that work on records in global memory */
 #endif
 
-namespace dcd {
+// Record geometry.  DCD_PITCH = 16 (default) is the layout described above: the hot path, grids up to 15 x 15.
+// The same logic compiled with DCD_PITCH = 32 / 64 / 128 (mg_big.hip, one namespace per pitch) serves the large
+// evaluation mazes (21, 51, 101 cells): PITCH rows of PITCH bytes, side column at x = PITCH-1 of rows 0..14,
+// dynamic state in the last 16 bytes.
+#ifndef DCD_PITCH
+#define DCD_PITCH 16
+#endif
+#if DCD_PITCH == 16
+#define DCD_NS dcd
+#elif DCD_PITCH == 32
+#define DCD_NS dcd_p32
+#elif DCD_PITCH == 64
+#define DCD_NS dcd_p64
+#elif DCD_PITCH == 128
+#define DCD_NS dcd_p128
+#else
+#error "DCD_PITCH must be 16, 32, 64 or 128"
+#endif
 
-constexpr int REC_BYTES = 256;
-constexpr int ROW = 16;
-constexpr int DYN = 240;
+namespace DCD_NS {
+
+constexpr int ROW = DCD_PITCH;
+constexpr int REC_BYTES = ROW * ROW;
+constexpr int DYN = REC_BYTES - 16;
+constexpr int SIDE = ROW - 1;
+constexpr int MAX_SIZE = ROW - 1;                  // largest grid this pitch holds
 constexpr uint8_t NOPOS = 0xFF;
 
 enum : uint8_t { C_NONE = 0, C_WALL0 = 1, C_FLOOR0 = 7, C_KEY0 = 13, C_BALL0 = 19, C_BOX0 = 25,
@@ -139,7 +160,7 @@ struct Env {
   float ep_ret;
 
   DCD_HDM DCD_REC uint8_t& cell(int x, int y) { return r[y * ROW + x]; }
-  DCD_HDM DCD_REC uint8_t& sb(int k) { return r[k * ROW + 15]; }
+  DCD_HDM DCD_REC uint8_t& sb(int k) { return r[k * ROW + SIDE]; }
   DCD_HDM void set_cell(int x, int y, uint8_t c) {
     const int o = y * ROW + x;
     r[o] = c;
@@ -210,6 +231,7 @@ DCD_HD void reset_metrics(Metrics& m, const Params& p) {           // adversaria
   m.shortest_path_length = (p.S - 2) * (p.S - 2) + 1;
 }
 
+#if DCD_PITCH == 16
 // _gen_grid (adversarial.py:166-172): border of grey walls, None inside.  Whole rows as four 32-bit words (the side
 // column byte at x = 15 is preserved); cells beyond S stay None.
 DCD_HD void gen_grid(Env& e, const Params& p) {
@@ -235,10 +257,19 @@ DCD_HD void gen_grid(Env& e, const Params& p) {
   }
   e.full_dirty = true;
 }
+#else
+DCD_HD void gen_grid(Env& e, const Params& p) {                          // _gen_grid (adversarial.py:166-172)
+  const int S = p.S;
+  for (int y = 0; y < S; ++y)
+    for (int x = 0; x < S; ++x)
+      e.cell(x, y) = (x == 0 || y == 0 || x == S - 1 || y == S - 1) ? C_WALL_GREY : C_NONE;
+  e.full_dirty = true;
+}
+#endif
 
 // bit x of the result: cell (x,y) is a wall (codes 1..6), x < S.  Byte-parallel range test: codes are < 0x80, so the
 // per-byte additions cannot carry into the neighbouring byte.
-DCD_HD uint32_t row_wall_mask(Env& e, int y, int S) {
+DCD_HD uint32_t row_wall_mask(Env& e, int y, int S) {                     // grids up to 15 wide (first 16 bytes of the row)
   const DCD_REC uint32_t* q = reinterpret_cast<const DCD_REC uint32_t*>(e.r + y * ROW);
   uint32_t m = 0;
 #pragma unroll
@@ -252,9 +283,10 @@ DCD_HD uint32_t row_wall_mask(Env& e, int y, int S) {
 
 // bit x of the result: cell (x,y) is None, x < S.  One 16-byte row read + exact zero-byte detection per dword
 // (the side column byte at x = 15 and the padding beyond S are masked off).
-DCD_HD uint32_t row_free_mask(Env& e, int y, int S) {
+// `chunk` selects cells [16*chunk, 16*chunk+16) of the row (always 0 at the default pitch).
+DCD_HD uint32_t row_free_mask(Env& e, int y, int S, int chunk = 0) {
   uint32_t w[4];
-  const DCD_REC uint32_t* q = reinterpret_cast<const DCD_REC uint32_t*>(e.r + y * ROW);      // rows are 16-byte aligned
+  const DCD_REC uint32_t* q = reinterpret_cast<const DCD_REC uint32_t*>(e.r + y * ROW + 16 * chunk);   // 16-byte aligned
   w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
   uint32_t m = 0;
 #pragma unroll
@@ -262,7 +294,8 @@ DCD_HD uint32_t row_free_mask(Env& e, int y, int S) {
     const uint32_t z = ~((((w[k] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w[k]) | 0x7F7F7F7Fu);      // 0x80 in every zero byte
     m |= ((((z >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * k);                                // gather the 4 flags
   }
-  return m & ((1u << S) - 1u);
+  const int left = S - 16 * chunk;                                 // cells of this chunk inside the grid
+  return left >= 16 ? m : (left <= 0 ? 0u : (m & ((1u << left) - 1u)));
 }
 
 // place_obj with top=None,size=None (multigrid.py:565-632): uniform over None cells != agent_pos,
@@ -271,25 +304,28 @@ DCD_HD uint32_t row_free_mask(Env& e, int y, int S) {
 DCD_HD bool place_uniform(Env& e, const Params& p, uint8_t code, int* px, int* py) {
   const int S = p.S;
   const int ex = e.has_pos() ? e.ax : -1, ey = e.ay;
+  constexpr int CH = ROW / 16;                               // 16-cell chunks per row (1 at the default pitch)
   int n = 0;
-  for (int y = 0; y < S; ++y) {
-    uint32_t m = row_free_mask(e, y, S);
-    if (y == ey && ex >= 0) m &= ~(1u << ex);
-    n += __builtin_popcount(m);
-  }
+  for (int y = 0; y < S; ++y)
+    for (int ch = 0; ch < CH; ++ch) {
+      uint32_t m = row_free_mask(e, y, S, ch);
+      if (y == ey && ex >= 0 && (ex >> 4) == ch) m &= ~(1u << (ex & 15));
+      n += __builtin_popcount(m);
+    }
   if (n == 0) { e.err |= DCD_ERR_NO_FREE_CELL; return false; }
   int k = randint(e, p, n);
-  for (int y = 0; y < S; ++y) {
-    uint32_t m = row_free_mask(e, y, S);
-    if (y == ey && ex >= 0) m &= ~(1u << ex);
-    const int c = __builtin_popcount(m);
-    if (k >= c) { k -= c; continue; }
-    for (; k > 0; --k) m &= m - 1;                           // drop the k lowest free cells of this row
-    const int x = __builtin_ctz(m);
-    if (code != C_NONE) e.set_cell(x, y, code);
-    *px = x; *py = y;
-    return true;
-  }
+  for (int y = 0; y < S; ++y)
+    for (int ch = 0; ch < CH; ++ch) {
+      uint32_t m = row_free_mask(e, y, S, ch);
+      if (y == ey && ex >= 0 && (ex >> 4) == ch) m &= ~(1u << (ex & 15));
+      const int c = __builtin_popcount(m);
+      if (k >= c) { k -= c; continue; }
+      for (; k > 0; --k) m &= m - 1;                         // drop the k lowest free cells of this chunk
+      const int x = 16 * ch + __builtin_ctz(m);
+      if (code != C_NONE) e.set_cell(x, y, code);
+      *px = x; *py = y;
+      return true;
+    }
   return false;
 }
 
@@ -322,6 +358,7 @@ DCD_HD void reset_agent(Env& e) {
 // wall nodes removed.  Bit-board BFS: one uint16 row mask per interior row (<= 13x13).
 DCD_HD void compute_metrics(Env& e, const Params& p, Metrics& m) {
   const int I = p.S - 2;
+  if (I > 13) return;      // large evaluation mazes (MazeEnv / MSTMazeEnv define no such metrics): defaults stay
   uint16_t fr[13], rc[13];
   int nw = 0;
 #pragma unroll
@@ -722,4 +759,4 @@ DCD_HD StepResult env_step(Env& e, const Params& p, Metrics& m, bool& metrics_di
   return env_step_post(e, p, m, metrics_dirty, flags, s);
 }
 
-}  // namespace dcd
+}  // namespace DCD_NS

@@ -547,7 +547,21 @@ __global__ void random_actions_kernel(int64_t* actions, int B, int T, long long 
 }  // namespace
 
 // =================================================================================== C ABI
+// large-grid variants (mg_big.hip, one build per record pitch); a handle created with size > 15 forwards to them
+#define DCD_BIG_DECL(P) \
+  int dcd_big_create_p##P(const DcdMgConfig*, int, void**); int dcd_big_destroy_p##P(void*); \
+  int dcd_big_set_seed_p##P(void*, const int64_t*, void*); int dcd_big_poll_errors_p##P(void*, uint32_t*, int32_t*, void*); \
+  int dcd_big_level_p##P(void*, int, const uint8_t*, const int32_t*, int32_t, const DcdStudentObs*, void*); \
+  int dcd_big_step_p##P(void*, const int64_t*, int32_t, const DcdStepOut*, void*); \
+  int dcd_big_get_encodings_p##P(void*, uint8_t*, void*); int dcd_big_get_state_p##P(void*, int32_t*, void*); \
+  int dcd_big_get_metrics_p##P(void*, int32_t*, int32_t*, int32_t*, int32_t*, void*);
+extern "C" { DCD_BIG_DECL(32) DCD_BIG_DECL(64) DCD_BIG_DECL(128) }
+#define BIG(h, fn, ...) ((h)->pitch == 32 ? fn##_p32((h)->big, __VA_ARGS__) : (h)->pitch == 64 ? fn##_p64((h)->big, __VA_ARGS__) : fn##_p128((h)->big, __VA_ARGS__))
+#define NO_BIG(h, what) do { if ((h)->big) return dcd::fail(what ": not available for grids above 15 x 15 (teacher-side op)"); } while (0)
+
 struct DcdMg {
+  void* big = nullptr;   // size > 15: the pitch-specific handle of mg_big.hip, everything below is unused
+  int pitch = 16;
   DcdMgConfig cfg;
   Params p;
   int device;
@@ -614,6 +628,15 @@ int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out) {
   HIP_OK(hipSetDevice(device));
   DcdMg* h = new DcdMg();
   h->cfg = *cfg; h->device = device;
+  if (cfg->size > MAX_SIZE) {                                      // large evaluation mazes: mg_big.hip
+    h->pitch = cfg->size <= 31 ? 32 : (cfg->size <= 63 ? 64 : 128);
+    h->p.B = cfg->num_envs; h->p.S = cfg->size; h->p.V = cfg->agent_view_size;
+    const int rc = h->pitch == 32 ? dcd_big_create_p32(cfg, device, &h->big)
+                 : h->pitch == 64 ? dcd_big_create_p64(cfg, device, &h->big) : dcd_big_create_p128(cfg, device, &h->big);
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return 0;
+  }
   static const int NEDIT[3] = {2, 3, 4};
   Params& p = h->p;
   p.B = cfg->num_envs; p.S = cfg->size; p.V = cfg->agent_view_size; p.max_steps = cfg->max_steps;
@@ -639,6 +662,11 @@ int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out) {
 
 int dcd_mg_destroy(DcdMg* h) {
   if (!h) return 0;
+  if (h->big) {
+    const int rc = h->pitch == 32 ? dcd_big_destroy_p32(h->big) : h->pitch == 64 ? dcd_big_destroy_p64(h->big) : dcd_big_destroy_p128(h->big);
+    delete h;
+    return rc;
+  }
   (void)hipSetDevice(h->device);
   (void)hipFree(h->rec); (void)hipFree(h->seed); (void)hipFree(h->met); (void)hipFree(h->errs);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -648,6 +676,7 @@ int dcd_mg_destroy(DcdMg* h) {
 
 int dcd_mg_set_seed(DcdMg* h, const int64_t* seeds, void* stream) {
   CHECK_H(h);
+  if (h->big) return BIG(h, dcd_big_set_seed, seeds, stream);
   hipLaunchKernelGGL(set_seed_kernel, dim3((h->p.B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->rec, h->seed, seeds, h->p.B);
   HIP_OK(hipGetLastError());
   return 0;
@@ -655,6 +684,7 @@ int dcd_mg_set_seed(DcdMg* h, const int64_t* seeds, void* stream) {
 
 int dcd_mg_poll_errors(DcdMg* h, uint32_t* err_bits, int32_t* first_env, void* stream) {
   CHECK_H(h);
+  if (h->big) return BIG(h, dcd_big_poll_errors, err_bits, first_env, stream);
   uint32_t host[2];
   HIP_OK(hipMemcpyAsync(host, h->errs, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_OK(hipStreamSynchronize((hipStream_t)stream));
@@ -670,27 +700,32 @@ int dcd_mg_poll_errors(DcdMg* h, uint32_t* err_bits, int32_t* first_env, void* s
 
 int dcd_mg_reset(DcdMg* h, const DcdAdvObs* out, void* stream) {
   CHECK_H(h);
+  NO_BIG(h, "dcd_mg_reset");
   LevelArgs a = base_args(h); if (out) a.adv = *out;
   return launch_level<OP_RESET>(h, a, stream);
 }
 int dcd_mg_step_adversary(DcdMg* h, const int64_t* loc, const DcdAdvObs* out, uint8_t* done, void* stream) {
   CHECK_H(h);
+  NO_BIG(h, "dcd_mg_step_adversary");
   if (!loc) return dcd::fail("dcd_mg_step_adversary: null loc");
   LevelArgs a = base_args(h); a.loc = loc; if (out) a.adv = *out; a.adv_done = done;
   return launch_level<OP_STEP_ADV>(h, a, stream);
 }
 int dcd_mg_reset_agent(DcdMg* h, const DcdStudentObs* out, void* stream) {
   CHECK_H(h);
+  if (h->big) return BIG(h, dcd_big_level, 1, nullptr, nullptr, h->p.B, out, stream);
   LevelArgs a = base_args(h); if (out) a.stu = *out;
   return launch_level<OP_RESET_AGENT>(h, a, stream);
 }
 int dcd_mg_reset_random(DcdMg* h, const DcdStudentObs* out, void* stream) {
   CHECK_H(h);
+  NO_BIG(h, "dcd_mg_reset_random");
   LevelArgs a = base_args(h); if (out) a.stu = *out;
   return launch_level<OP_RESET_RANDOM>(h, a, stream);
 }
 int dcd_mg_reset_to_encoding(DcdMg* h, const uint8_t* enc, const int32_t* idx, int32_t n, const DcdStudentObs* out, void* stream) {
   CHECK_H(h);
+  NO_BIG(h, "dcd_mg_reset_to_encoding");
   if (!enc) return dcd::fail("dcd_mg_reset_to_encoding: null enc");
   if (n < 0 || (!idx && n != h->p.B)) return dcd::fail("dcd_mg_reset_to_encoding: n=%d must equal num_envs=%d when idx is NULL", n, h->p.B);
   LevelArgs a = base_args(h); a.enc = enc; a.idx = idx; a.n_rows = n; if (out) a.stu = *out;
@@ -700,6 +735,7 @@ int dcd_mg_reset_to_fixed_level(DcdMg* h, const uint8_t* enc, const int32_t* idx
   CHECK_H(h);
   if (!enc) return dcd::fail("dcd_mg_reset_to_fixed_level: null enc");
   if (n < 0 || (!idx && n != h->p.B)) return dcd::fail("dcd_mg_reset_to_fixed_level: n=%d must equal num_envs=%d when idx is NULL", n, h->p.B);
+  if (h->big) return BIG(h, dcd_big_level, 0, enc, idx, n, out, stream);
   LevelArgs a = base_args(h); a.enc = enc; a.idx = idx; a.n_rows = n; if (out) a.stu = *out;
   return launch_level<OP_FIXED_LEVEL>(h, a, stream);
 }
@@ -707,12 +743,14 @@ int dcd_mg_reset_to_actions(DcdMg* h, const int64_t* actions, const int32_t* len
                             const DcdStudentObs* out, void* stream) {
   CHECK_H(h);
   if (!actions || !lens) return dcd::fail("dcd_mg_reset_to_actions: null actions/lens");
+  NO_BIG(h, "dcd_mg_reset_to_actions");
   if (n < 0 || (!idx && n != h->p.B)) return dcd::fail("dcd_mg_reset_to_actions: n=%d must equal num_envs=%d when idx is NULL", n, h->p.B);
   LevelArgs a = base_args(h); a.loc = actions; a.lens = lens; a.max_len = max_len; a.idx = idx; a.n_rows = n; if (out) a.stu = *out;
   return launch_level<OP_REPLAY>(h, a, stream);
 }
 int dcd_mg_mutate_level(DcdMg* h, int32_t num_edits, const DcdStudentObs* out, void* stream) {
   CHECK_H(h);
+  NO_BIG(h, "dcd_mg_mutate_level");
   if (num_edits < 0 || num_edits > 64) return dcd::fail("num_edits %d outside [0,64]", num_edits);
   LevelArgs a = base_args(h); a.num_edits = num_edits; if (out) a.stu = *out;
   return launch_level<OP_MUTATE>(h, a, stream);
@@ -721,6 +759,7 @@ int dcd_mg_mutate_level(DcdMg* h, int32_t num_edits, const DcdStudentObs* out, v
 int dcd_mg_step(DcdMg* h, const int64_t* actions, int32_t flags, const DcdStepOut* out, void* stream) {
   CHECK_H(h);
   if (!actions) return dcd::fail("dcd_mg_step: null actions");
+  if (h->big) return BIG(h, dcd_big_step, actions, flags, out, stream);
   StepArgs a; memset(&a, 0, sizeof a);
   a.rec = h->rec; a.seed = h->seed; a.met = h->met; a.errs = h->errs; a.actions = actions; a.flags = flags;
   a.stamps = h->stamps;
@@ -744,6 +783,7 @@ int dcd_internal_set_stamps(DcdMg* h, unsigned long long* dev_ptr) { if (!h) ret
 
 int dcd_mg_profile_begin(DcdMg* h, int32_t capacity) {
   CHECK_H(h);
+  NO_BIG(h, "dcd_mg_profile_begin");
   if (capacity <= 0 || capacity > (1 << 20)) return dcd::fail("dcd_mg_profile_begin: bad capacity %d", capacity);
   while ((int)h->ev.size() < 2 * capacity) {
     hipEvent_t e;
@@ -774,6 +814,7 @@ int dcd_mg_step_random(DcdMg* h, uint32_t action_seed, uint32_t t0, int32_t K, i
                        int64_t* n_episodes, void* stream) {
   CHECK_H(h);
   if (K <= 0) return dcd::fail("dcd_mg_step_random: K must be > 0");
+  NO_BIG(h, "dcd_mg_step_random");
   StepArgs a; memset(&a, 0, sizeof a);
   a.rec = h->rec; a.seed = h->seed; a.met = h->met; a.errs = h->errs; a.flags = flags;
   a.K = K; a.action_seed = action_seed; a.t0 = t0; a.env_index_base = h->cfg.env_index_base;
@@ -794,11 +835,13 @@ int dcd_mg_step_random(DcdMg* h, uint32_t action_seed, uint32_t t0, int32_t K, i
 int dcd_mg_get_encodings(DcdMg* h, uint8_t* out, void* stream) {
   CHECK_H(h);
   if (!out) return dcd::fail("dcd_mg_get_encodings: null out");
+  if (h->big) return BIG(h, dcd_big_get_encodings, out, stream);
   LevelArgs a = base_args(h); a.enc_out = out;
   return launch_level<OP_READ_ENC>(h, a, stream);
 }
 int dcd_mg_get_metrics(DcdMg* h, int32_t* ncl, int32_t* pas, int32_t* spl, int32_t* dist, void* stream) {
   CHECK_H(h);
+  if (h->big) return BIG(h, dcd_big_get_metrics, ncl, pas, spl, dist, stream);
   hipLaunchKernelGGL(get_metrics_kernel, dim3((h->p.B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->p.B, h->met, ncl, pas, spl, dist);
   HIP_OK(hipGetLastError());
   return 0;
@@ -806,6 +849,7 @@ int dcd_mg_get_metrics(DcdMg* h, int32_t* ncl, int32_t* pas, int32_t* spl, int32
 int dcd_mg_get_state(DcdMg* h, int32_t* out, void* stream) {
   CHECK_H(h);
   if (!out) return dcd::fail("dcd_mg_get_state: null out");
+  if (h->big) return BIG(h, dcd_big_get_state, out, stream);
   hipLaunchKernelGGL(get_state_kernel, dim3((h->p.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, h->p, h->rec, out);
   HIP_OK(hipGetLastError());
   return 0;

@@ -220,8 +220,8 @@ class MazeEnv:
         bit_map = np.asarray(bit_map)
         if bit_map.shape != (size - 2, size - 2):
             raise ValueError(f"bit map {bit_map.shape} does not match size {size}")
-        if size > 15:
-            raise NotImplementedError(f"{type(self).__name__}: {size}x{size} grids exceed the engine's 15x15 record layout")
+        if size > 127:
+            raise NotImplementedError(f"{type(self).__name__}: {size}x{size} grids exceed the engine's widest record (127)")
         self.bit_map = bit_map
         self.size = self.width = self.height = size
         self.agent_view_size = agent_view_size
@@ -236,6 +236,7 @@ class MazeEnv:
         self.goal_pos = tuple(goal_pos)
         self.n_agents, self.minigrid_mode, self.see_through_walls = 1, minigrid_mode, True
         self.seed_value = seed
+        self.is_procedural = False
         self.spec = None
         self._max_episode_steps = None
         self.action_space = spaces.Discrete(7)

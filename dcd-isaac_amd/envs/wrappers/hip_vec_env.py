@@ -48,9 +48,15 @@ class HipAdversarialVecEnv:
         self.observation_space = {"image": spaces.Box(0, 255, (3, V, V), "uint8"),
                                   "direction": p.observation_space["direction"]}
         self.is_fixed_level = bool(getattr(p, "is_fixed_level", False))
+        # procedural families (mst_maze.py, cluttered.py): `_gen_grid` draws a NEW level on every reset in the reference,
+        # so a level is regenerated on the host and re-uploaded whenever an episode ends (new_levels)
+        self.is_procedural = bool(getattr(p, "is_procedural", False))
         if self.is_fixed_level:
             # evaluation mazes (envs/multigrid/maze.py): one description per env (corridor goals differ per env)
-            descs = [self.proto] + [fn() for fn in env_fns[1:]]
+            self._descs = descs = [self.proto] + [fn() for fn in env_fns[1:]]
+            if self.is_procedural:
+                for i, d in enumerate(descs):                     # per-env generator streams (worker seeds, parallel_wrappers.py:414)
+                    d.seed((int(engine_seed) * 1000003 + self.env_index_base + i) & 0x7FFFFFFF)
             self._fixed_levels = torch.from_numpy(np.stack([d.level_encoding() for d in descs])).to(self.device)
             self.adversary_action_space = None
             self.adversary_observation_space = None
@@ -116,10 +122,22 @@ class HipAdversarialVecEnv:
         MultiGridEnv.reset — reload the level, student obs (eval.py:266)."""
         self._assert_not_closed()
         if self.is_fixed_level:
+            if self.is_procedural:
+                self._fixed_levels.copy_(torch.from_numpy(np.stack([d.level_encoding() for d in self._descs])))
             out = self.engine.reset_to_fixed_level(self._fixed_levels, None, self._student_out())
             self.raise_errors()
             return self._student_dict(out)
         return self._adv_dict(self.engine.reset(self.engine.adv_buffers(u8=False)))
+
+    def new_levels(self, idx):
+        """Procedural families: the envs `idx` (list of ints) finished an episode — the worker's env.reset()
+        (parallel_wrappers.py:20-25) draws a new level for each.  Returns their first observations (rows in idx order)."""
+        idx = [int(i) for i in idx]
+        enc = torch.from_numpy(np.stack([self._descs[i].level_encoding() for i in idx])).to(self.device)
+        it = torch.tensor(idx, dtype=torch.int32, device=self.device)
+        self._fixed_levels[it.long()] = enc
+        out = self.engine.reset_to_fixed_level(enc, it, self._student_out(len(idx)))
+        return self._student_dict(out)
 
     def step(self, actions):
         """VecEnv.step of the evaluation path (worker `step`, parallel_wrappers.py:20-25: env.reset() on done).
@@ -219,6 +237,12 @@ class HipAdversarialVecEnv:
                 d["episode"] = {"r": ep_ret[i], "l": int(ep_len[i]), "t": 0.0}
             infos.append(d)
         obs = {k: v.clone() for k, v in self._student_dict(out["obs"]).items()}
+        if self.is_procedural and done.any():                     # env.reset() of a procedural family: a new level
+            idx = np.nonzero(done)[0].tolist()
+            first = self.new_levels(idx)
+            for k in obs:
+                obs[k][idx] = first[k]
+            self.raise_errors()
         return obs, out["reward"].clone().unsqueeze(1), done, infos
 
     def step_env_async(self, action):

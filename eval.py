@@ -33,13 +33,22 @@ class Evaluator:
         self.num_episodes = num_episodes
         self.device = torch.device(device)
         self.solved_threshold = 0
+        self._fused = {}
         self.venv = {}
         for name in self.env_names:
             if not name.startswith("MultiGrid"):
-                raise ValueError(f"{name}: only the MultiGrid evaluation mazes are built (SURVEY §8f-2)")
+                raise ValueError(f"{name}: only the MultiGrid evaluation families are built (SURVEY §8f-2)")
             make_fn = [lambda n=name: gym_make(n)] * num_processes
             self.venv[name] = HipAdversarialVecEnv(make_fn, adversary=False, is_eval=True, device=device)
         self.is_discrete_actions = is_discrete_actions(self.venv[self.env_names[0]])
+
+    def _fused_actor(self, net, B):
+        from dcd_hip.policy import StudentActor
+        key = (id(net), B)
+        if key not in self._fused:
+            self._fused[key] = StudentActor.try_create(net, B, seed=0xE7A1)
+        fa = self._fused[key]
+        return None if (fa is None or net.random) else fa
 
     def get_stats_keys(self):
         keys = []
@@ -64,9 +73,22 @@ class Evaluator:
                 hxs = (hxs, torch.zeros_like(hxs))
             masks = torch.ones(B, 1, device=dev)
             out = venv.engine.step_buffers(u8=False)
+            fused = self._fused_actor(net, B)
+            if fused is not None:                                    # policy step on the HIP path (dcd_hip.policy)
+                fused.begin_rollout(1 << 20)
+                hc = [torch.zeros(B, 2 * H, device=dev) for _ in range(2)]
+                fo = dict(value=torch.zeros(B, 1, device=dev), action=torch.zeros(B, 1, dtype=torch.int64, device=dev),
+                          logp=torch.zeros(B, 1, device=dev), log_dist=torch.zeros(B, net.action_space.n, device=dev))
+                t = 0
             while len(returns) < self.num_episodes:
-                with torch.no_grad():
-                    _, action, _, hxs = agent.act(obs, hxs, masks, deterministic=deterministic)
+                if fused is not None:
+                    fused.counter = t
+                    fused.act_into(obs["image"], obs["direction"], hc[t & 1], masks, hc[(t + 1) & 1], fo["value"], fo["action"],
+                                   fo["logp"], fo["log_dist"], deterministic=deterministic)
+                    action, t = fo["action"], t + 1
+                else:
+                    with torch.no_grad():
+                        _, action, _, hxs = agent.act(obs, hxs, masks, deterministic=deterministic)
                 venv.step_env_device(action.view(-1), out)
                 obs = {"image": out["obs"]["image_f32"], "direction": out["obs"]["dir_f32"]}
                 masks = out["masks"].view(B, 1).clone()
@@ -75,7 +97,14 @@ class Evaluator:
                 if idx.numel():
                     if agent.is_recurrent:                       # eval.py:303-305
                         keep = (~finished).float().view(B, 1)
-                        hxs = tuple(h * keep for h in hxs) if isinstance(hxs, tuple) else hxs * keep
+                        if fused is not None:
+                            hc[t & 1].mul_(keep)
+                        else:
+                            hxs = tuple(h * keep for h in hxs) if isinstance(hxs, tuple) else hxs * keep
+                    if venv.is_procedural:                       # the worker's env.reset() draws a new level
+                        first = venv.new_levels(idx.cpu().tolist())
+                        obs["image"][idx] = first["image"]
+                        obs["direction"][idx] = first["direction"]
                     for r in out["ep_ret"][idx].cpu().tolist():  # env order, as the reference's loop over infos
                         returns.append(r)
                         solved += int(r > self.solved_threshold)

@@ -47,7 +47,7 @@ enum {
 enum { DCD_ACT_LEFT = 0, DCD_ACT_RIGHT = 1, DCD_ACT_FORWARD = 2, DCD_ACT_PICKUP = 3,
        DCD_ACT_DROP = 4, DCD_ACT_TOGGLE = 5, DCD_ACT_DONE = 6 };
 
-#define DCD_MAX_GRID 15   /* registered adversarial ids use size 6, 10, 15 */
+#define DCD_MAX_GRID 127  /* adversarial ids: 6, 10, 15 (the tuned 256-byte record); evaluation mazes up to 101 use wider records */
 #define DCD_MAX_VIEW 7
 
 /* per-env error bits latched on device (dcd_mg_poll_errors) */
@@ -81,7 +81,7 @@ enum {
  * (util/__init__.py:213-217). */
 typedef struct DcdMgConfig {
   int32_t  num_envs;            /* B on this device */
-  int32_t  size;                /* grid width == height, 3..15 */
+  int32_t  size;                /* grid width == height, 3..127; teacher-side calls need size <= 15 */
   int32_t  agent_view_size;     /* V, odd, 3..7 (all registered ids: 5) */
   int32_t  max_steps;           /* MultiGridEnv.max_steps (multigrid.py:448,972) */
   int32_t  max_episode_steps;   /* TimeLimit; <=0: no wrapper */

@@ -300,6 +300,9 @@ static void compute_metrics(Env* e) {
     Obj o = grid_get(e, x + 1, y + 1);
     if (o.present && o.type == DCD_OBJ_WALL) ++n;                         /* isinstance(x, Wall) */
   }
+  /* Grids above 15 x 15 exist only as MazeEnv / MSTMazeEnv evaluation levels, which define no such metrics
+   * (maze.py, mst_maze.py): the defaults stay, as in the engine. */
+  if (IW > 13) return;
   e->n_clutter_placed = n;
   if (!e->has_start || !e->has_goal) return;                              /* :424-425 */
   e->distance_to_goal = abs(e->gx - e->sx) + abs(e->gy - e->sy);

@@ -12,7 +12,7 @@
 #include <vector>
 #include "../../dcd-isaac_amd/csrc/mg_env.h"
 
-using namespace dcd;
+using namespace DCD_NS;
 
 struct SimMg {
   DcdMgConfig cfg;
@@ -63,7 +63,7 @@ static void emit_adv_row(SimMg* h, Env& e, int row, const DcdAdvObs* o, const fl
 extern "C" {
 
 SimMg* sim_mg_create(const DcdMgConfig* cfg) {
-  if (!cfg || cfg->size < 3 || cfg->size > DCD_MAX_GRID || !(cfg->agent_view_size & 1) || cfg->random_z_dim > 52) return nullptr;
+  if (!cfg || cfg->size < 3 || cfg->size > MAX_SIZE || !(cfg->agent_view_size & 1) || cfg->random_z_dim > 52) return nullptr;
   SimMg* h = new SimMg();
   h->cfg = *cfg;
   static const int NEDIT[3] = {2, 3, 4};

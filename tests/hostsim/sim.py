@@ -13,15 +13,18 @@ _LIB = os.path.join(_HERE, "libhostsim.so")
 _lib = None
 
 
-def build(sanitize=False):
+def build(sanitize=False, pitch=16):
+    """pitch: record pitch the env logic is compiled for (16: grids up to 15; 32 / 64 / 128: the large mazes)."""
     src = os.path.join(_HERE, "hostsim.cpp")
     hdr = os.path.join(_HERE, "..", "..", "dcd-isaac_amd", "csrc", "mg_env.h")
     out = _LIB if not sanitize else os.path.join(_HERE, "libhostsim_asan.so")
+    if pitch != 16:
+        out = out.replace(".so", f"_p{pitch}.so")
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
         return out
     flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else ["-O2"]
     subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
-                           *flags, "-o", out, src])
+                           f"-DDCD_PITCH={pitch}", *flags, "-o", out, src])
     return out
 
 
@@ -40,3 +43,20 @@ class HostSimMg(orc.OracleMg):
     @staticmethod
     def _library():
         return lib()
+
+
+_big = {}
+
+
+def big_lib(pitch):
+    if pitch not in _big:
+        l = C.CDLL(build(pitch=pitch))
+        l.sim_mg_create.restype = C.c_void_p
+        l.sim_mg_poll_errors.restype = C.c_uint32
+        _big[pitch] = l
+    return _big[pitch]
+
+
+def host_sim_class(pitch):
+    """HostSimMg over the env logic compiled for a wider record pitch (grids above 15 x 15)."""
+    return type(f"HostSimMgP{pitch}", (HostSimMg,), {"_library": staticmethod(lambda: big_lib(pitch))})

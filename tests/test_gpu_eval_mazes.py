@@ -56,3 +56,44 @@ def test_evaluator_interface():
     raw = ev.evaluate(agent, accumulator=None)
     assert all(len(raw[f"test_returns:{n}"]) == 40 for n in names)
     ev.close(); venv.close()
+
+
+# ---- grids above 15 x 15 (csrc/mg_big.hip: the env logic at record pitch 32 / 64 / 128) and procedural families -------
+@pytest.mark.parametrize("name,B", [("MultiGrid-LargeCorridor-v0", 33), ("MultiGrid-PerfectMazeMedium-v0", 70),
+                                    ("MultiGrid-PerfectMazeLarge-v0", 20), ("MultiGrid-PerfectMazeXL-v0", 5)])
+def test_large_maze_rollout_matches_oracle(name, B):
+    from tests.hip_adapter import HipMg
+    from tests.test_big_grids import _levels, rollout_matches
+    descs, enc = _levels(name, B, seed=7)
+    cfg = dict(num_envs=B, **descs[0].engine_config())
+    cfg["max_episode_steps"] = 150
+    x, y = orc.OracleMg(**cfg), HipMg(**cfg)
+    rollout_matches(x, y, enc, 400, np.random.default_rng(B))
+
+
+def test_teacher_ops_refuse_large_grids():
+    import dcd_hip
+    eng = dcd_hip.MultiGridEngine(4, size=21, n_clutter=0, random_z_dim=0, editor_actions=0)
+    with pytest.raises(dcd_hip.DcdHipError, match="not available for grids above 15 x 15"):
+        eng.reset_random()
+    eng.close()
+
+
+def test_evaluator_on_procedural_and_large_families():
+    ev_mod = __import__("eval")
+    from arguments import parser
+    from util import create_parallel_env, make_agent
+    args = parser.parse_args([])
+    args.num_processes = 16
+    venv, _ = create_parallel_env(args, device="cuda:0")
+    agent = make_agent("agent", venv, args, "cuda:0")
+    names = ["MultiGrid-PerfectMazeSmall-v0", "MultiGrid-PerfectMazeMedium-v0", "MultiGrid-LargeCorridor-v0",
+             "MultiGrid-MiniCluttered6-Minigrid-v0"]
+    ev = ev_mod.Evaluator(names, num_processes=16, num_episodes=20, device="cuda:0")
+    assert ev.venv[names[0]].is_procedural and not ev.venv[names[2]].is_procedural
+    before = ev.venv[names[3]]._fixed_levels.clone()
+    stats = ev.evaluate(agent)
+    for n in names:
+        assert 0.0 <= stats[f"solved_rate:{n}"] <= 1.0 and 0.0 <= stats[f"test_returns:{n}"] <= 1.0
+    assert not torch.equal(before, ev.venv[names[3]]._fixed_levels)    # finished episodes drew new levels
+    ev.close(); venv.close()

@@ -7,8 +7,12 @@ import torch
 csrc = os.path.join(ROOT, "dcd-isaac_amd", "csrc")
 out = os.path.join(ROOT, "gpurun_out", "libdcd_hip_stamps.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                       "-DDCD_STAMPS", "-shared", "-o", out, os.path.join(csrc, "mg_kernels.hip"), os.path.join(csrc, "scan_kernels.hip")])
+subprocess.check_call(["make", "-C", csrc], stdout=subprocess.DEVNULL)            # the other objects, unchanged
+obj = out.replace(".so", "_mg_kernels.o")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                       "-DDCD_STAMPS", "-c", "-o", obj, os.path.join(csrc, "mg_kernels.hip")])
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out, obj] +
+                      [os.path.join(csrc, f) for f in ("scan_kernels.o", "policy_kernels.o", "mg_big_p32.o", "mg_big_p64.o", "mg_big_p128.o")])
 import dcd_hip
 dcd_hip.LIB_PATH = out
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
