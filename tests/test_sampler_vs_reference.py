@@ -109,3 +109,41 @@ def test_level_store_matches_reference():
     st2 = LevelStore(data_info={"numpy": True, "dtype": enc.dtype, "shape": enc.shape})
     sid = st2.insert([enc.tobytes()])
     assert np.array_equal(st2.get_level(sid[0]), s["bytes_roundtrip"])
+
+
+@pytest.mark.parametrize("score_transform,staleness_coef,staleness_transform", [
+    ("rank", 0.3, "power"), ("rank", 0.0, "power"), ("power", 0.3, "power"), ("softmax", 0.5, "rank"),
+    ("eps_greedy", 0.3, "power"), ("match_rank", 0.1, "power"), ("max", 0.3, "power")])
+def test_batched_replay_sampling_equals_sequential_calls(score_transform, staleness_coef, staleness_transform):
+    """sample_replay_levels(n) (one pass over the unchanging score weights, hand-rolled inverse-CDF draw) is the same
+    function as n calls of sample_replay_level(): same seeds, same global-RNG state afterwards, same staleness."""
+    from level_replay import LevelSampler
+
+    class Space:
+        n = 7
+
+    def make():
+        s = LevelSampler([], None, Space(), num_actors=4, strategy="positive_value_loss", score_transform=score_transform,
+                         temperature=0.3, staleness_coef=staleness_coef, staleness_transform=staleness_transform,
+                         staleness_temperature=1.0, sample_full_distribution=True, seed_buffer_size=300, rho=0.5, replay_prob=0.5)
+        rng = np.random.default_rng(5)
+        N = 300
+        s.seeds[:] = np.arange(11, N + 11)
+        s.seed2index = {int(sd): i for i, sd in enumerate(s.seeds)}
+        s.seed_scores[:] = rng.random(N) * (rng.random(N) > 0.1)
+        s.unseen_seed_weights[:] = (rng.random(N) > 0.8).astype(np.float64)
+        s.seed_staleness[:] = rng.integers(0, 40, N)
+        s.working_seed_buffer_size = N
+        return s
+
+    a, b = make(), make()
+    np.random.seed(123)
+    seq = [a.sample_replay_level() for _ in range(200)]
+    state_a = np.random.get_state()[1].copy()
+    np.random.seed(123)
+    bat = b.sample_replay_levels(200)
+    state_b = np.random.get_state()[1].copy()
+    assert seq == bat
+    assert np.array_equal(state_a, state_b)
+    assert np.array_equal(a.seed_staleness, b.seed_staleness)
+    assert all(a.unseen_seed_weights[a.seed2index[sd]] == 0 for sd in bat)      # only seen levels are replayed
