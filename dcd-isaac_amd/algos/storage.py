@@ -235,22 +235,29 @@ class RolloutStorage:
             for i, t in enumerate(done_steps[:-1]):
                 yield b, " ".join(str(a) for a in acts[t:done_steps[i + 1], b])
 
+    def _action_complexity(self, per_env):
+        """dcd_action_complexity (csrc/host_utils.cpp): the per-character LZ76 loop in C, on host copies of the
+        action and mask buffers (1M characters per rollout at 4096 envs: 0.37 s in Python)."""
+        import ctypes as C
+        import numpy as np
+        from dcd_hip import check, lib
+        acts = np.ascontiguousarray(self.actions[:, :, 0].cpu().numpy().astype(np.int64))
+        masks = np.ascontiguousarray(self.masks[:, :, 0].cpu().numpy().astype(np.float32))
+        T, B = acts.shape
+        total, n = C.c_double(0), C.c_int64(0)
+        env = np.zeros(B, np.float32) if per_env else None
+        check(lib().dcd_action_complexity(acts.ctypes.data_as(C.c_void_p), masks.ctypes.data_as(C.c_void_p), C.c_int32(T),
+                                          C.c_int32(B), C.byref(total), C.byref(n),
+                                          env.ctypes.data_as(C.c_void_p) if per_env else None))
+        return total.value, n.value, env
+
     def get_action_complexity(self):
-        total, n = 0, 0
-        for _, s in self._episode_action_strings():
-            total += lempel_ziv_complexity(s)
-            n += 1
+        total, n, _ = self._action_complexity(False)
         return total / max(n, 1)
 
     def get_batched_action_complexity(self):
-        out = torch.zeros(self.actions.shape[1], 1)
-        sums, counts = defaultdict(float), defaultdict(int)
-        for b, s in self._episode_action_strings():
-            sums[b] += lempel_ziv_complexity(s)
-            counts[b] += 1
-        for b in counts:
-            out[b] = sums[b] / counts[b]
-        return out
+        _, _, env = self._action_complexity(True)
+        return torch.from_numpy(env).view(-1, 1)
 
     # ---- recurrent state helpers ----------------------------------------------------------------
     def _split_batched_lstm_recurrent_hidden_states(self, hxs):

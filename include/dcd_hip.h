@@ -360,6 +360,14 @@ int dcd_lstm_seq_bwd_step(const float* act, const float* c_t, const float* c_pre
                           const float* dh_last, const float* dc_last, float* dgates, float* dcf, int32_t N,
                           int32_t H, void* stream);
 
+/* ---- logging statistics (HOST pointers — the only entry point that is not a device call) ------------------ */
+/* RolloutStorage.get_action_complexity / get_batched_action_complexity (algos/storage.py:329-369): LZ76 phrase
+ * count (the `lempel_ziv_complexity` package, storage.py:21) of every episode's action string "a0 a1 ...";
+ * episodes are cut at done_steps = [0] + {t : masks[t,b] == 0}.  actions int64[T,B], masks float[T+1,B] in HOST
+ * memory; total = sum over episodes, n_episodes their number, per_env float[B] = per-env mean (may be NULL). */
+int dcd_action_complexity(const int64_t* actions, const float* masks, int32_t T, int32_t B, double* total,
+                          int64_t* n_episodes, float* per_env);
+
 /* ---- synthetic workload helpers (bench / tests only) ------------- */
 /* actions[t,i] = mulhi(philox(key=(seed, env_index_base+i), ctr=(t0+t,0,0,0))[0], num_actions);
  * actions: int64[T,B] */

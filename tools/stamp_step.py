@@ -12,7 +12,7 @@ obj = out.replace(".so", "_mg_kernels.o")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
                        "-DDCD_STAMPS", "-c", "-o", obj, os.path.join(csrc, "mg_kernels.hip")])
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out, obj] +
-                      [os.path.join(csrc, f) for f in ("scan_kernels.o", "policy_kernels.o", "mg_big_p32.o", "mg_big_p64.o", "mg_big_p128.o")])
+                      [os.path.join(csrc, f) for f in ("scan_kernels.o", "policy_kernels.o", "host_utils.o", "mg_big_p32.o", "mg_big_p64.o", "mg_big_p128.o")])
 import dcd_hip
 dcd_hip.LIB_PATH = out
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

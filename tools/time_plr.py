@@ -1,0 +1,32 @@
+"""Robust PLR (BASELINE config 3 shape: mg_25b_robust_plr.json) at B = 4096, T = 256 on one GPU: seconds per update,
+replay vs exploratory, with the host-side phases of the level sampler broken out."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dcd-isaac_amd")); sys.path.insert(0, ROOT)
+import numpy as np, torch
+from arguments import parser
+from envs.runners import AdversarialRunner
+from util import create_parallel_env, make_agent, make_plr_args, seed
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+flags = json.load(open(os.path.join(ROOT, "tests", "golden", "mg_train_configs.json")))["25_blocks/mg_25b_robust_plr.json"]
+args = parser.parse_args([f"--{k}={v}" for k, v in flags.items()])
+args.num_processes = B
+args.level_replay_rho = 0.2                    # start replaying once 800 of the 4000 buffer slots are filled
+seed(1)
+dev = "cuda:0"
+venv, ued = create_parallel_env(args, device=dev)
+agent = make_agent("agent", venv, args, dev); teacher = make_agent("adversary_env", venv, args, dev); teacher.random()
+runner = AdversarialRunner(args=args, venv=venv, agent=agent, ued_venv=ued, adversary_env=teacher, train=True,
+                           plr_args=make_plr_args(args, venv.observation_space, venv.action_space), device=dev)
+import cProfile, pstats
+for j in range(10):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    if j == 8:
+        pr = cProfile.Profile(); pr.enable()
+    stats = runner.run()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    if j == 8:
+        pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+    print(json.dumps({"update": j, "replay": bool(runner.sampled_level_info["level_replay"]), "seconds": round(dt, 3),
+                      "env_steps_per_s": round(B * 256 / dt), "buffer": int(runner.level_samplers["agent"].working_seed_buffer_size)}), flush=True)
