@@ -407,16 +407,16 @@ class LevelSampler:
             else:
                 w = ws
             total = np.sum(w)
-            if np.isclose(total, 0):
+            if abs(total) <= 1e-8:                                   # np.isclose(total, 0) for a scalar
                 w = np.ones_like(self.seeds, dtype=np.float64) / N
                 w = w * unseen_keep
                 w /= np.sum(w)
             elif total != 1.0:
                 w = w / total
-            if not (abs(np.sum(w) - 1.0) <= 1e-8) or (w < 0).any():  # let numpy raise exactly as the sequential path would
+            cdf = w.cumsum()
+            if not (abs(cdf[-1] - 1.0) <= 1e-8) or w.min() < 0:     # let numpy raise exactly as the sequential path would
                 seed_idx = np.random.choice(range(N), 1, p=w)[0]
             else:
-                cdf = w.cumsum()
                 cdf /= cdf[-1]
                 seed_idx = int(cdf.searchsorted(np.random.random_sample(1), side="right")[0])
             if update_staleness:

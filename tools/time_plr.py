@@ -20,13 +20,19 @@ agent = make_agent("agent", venv, args, dev); teacher = make_agent("adversary_en
 runner = AdversarialRunner(args=args, venv=venv, agent=agent, ued_venv=ued, adversary_env=teacher, train=True,
                            plr_args=make_plr_args(args, venv.observation_space, venv.action_space), device=dev)
 import cProfile, pstats
-for j in range(10):
+prof_replay = prof_explore = False
+for j in range(12):
     torch.cuda.synchronize(); t = time.perf_counter()
-    if j == 8:
-        pr = cProfile.Profile(); pr.enable()
+    pr = cProfile.Profile() if j >= 4 else None
+    if pr: pr.enable()
     stats = runner.run()
     torch.cuda.synchronize(); dt = time.perf_counter() - t
-    if j == 8:
-        pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+    if pr:
+        pr.disable()
+        rep = bool(runner.sampled_level_info["level_replay"])
+        if (rep and not prof_replay) or (not rep and not prof_explore):
+            print("---- profile of a", "replay" if rep else "exploratory", "update")
+            pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+            prof_replay, prof_explore = prof_replay or rep, prof_explore or not rep
     print(json.dumps({"update": j, "replay": bool(runner.sampled_level_info["level_replay"]), "seconds": round(dt, 3),
                       "env_steps_per_s": round(B * 256 / dt), "buffer": int(runner.level_samplers["agent"].working_seed_buffer_size)}), flush=True)
