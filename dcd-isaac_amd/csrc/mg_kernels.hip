@@ -218,8 +218,14 @@ struct StepRes { float reward, ep_ret; int ep_len; uint32_t flags; uint32_t doff
 // RR: the launch may auto-reset finished envs to RANDOM levels (DR without PLR).  A compile-time flag because that
 // path inlines reset_random + the BFS metrics: the other variant is a third of the code (instruction-cache misses
 // on cold paths were a visible part of the slowest workgroup's time).
+// The first four arguments repeat a.rec / a.seed / a.actions / p.B as plain scalars: with
+// -amdgpu-kernarg-preload-count they arrive in SGPRs at wave launch (struct arguments are not preloaded), so the
+// record / seed / action loads are issued without waiting for a kernarg fetch first.
 template <bool RANDOM, int EPB, bool RR>
-__global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel(Params p, StepArgs a) {
+__global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel(const uint8_t* __restrict__ rec_in,
+                                                                                 const uint32_t* __restrict__ seed_in,
+                                                                                 const int64_t* __restrict__ actions_in, int B_in,
+                                                                                 Params p, StepArgs a) {
   constexpr int NT = Threads<EPB>::value;
   __shared__ __attribute__((aligned(16))) uint8_t lds[EPB * LP];
   __shared__ __attribute__((aligned(16))) uint8_t sterm[EPB * MAX_OP];
@@ -228,14 +234,14 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
   __shared__ int any_term;
   __shared__ Luts lut;
   const int tid = threadIdx.x, env0 = blockIdx.x * EPB;
-  const int n = min(EPB, p.B - env0), env = env0 + tid;
-  const int OP = obs_pitch(p.V);
+  const int n = min(EPB, B_in - env0), env = env0 + tid;
   STAMP(0);
   // issue every independent global load up front: records, action, seed (one HBM round trip in all)
   StageBuf<EPB, NT> sb;
-  if (tid < NT) stage_load<EPB, NT>(sb, a.rec, [env0](int row) { return env0 + row; }, n, tid);
+  if (tid < NT) stage_load<EPB, NT>(sb, rec_in, [env0](int row) { return env0 + row; }, n, tid);
   int64_t act0 = 0; uint32_t seed = 0;
-  if (tid < n) { seed = a.seed[env]; if (!RANDOM) act0 = a.actions[env]; term_valid[tid] = 0; }
+  if (tid < n) { seed = seed_in[env]; if (!RANDOM) act0 = actions_in[env]; term_valid[tid] = 0; }
+  const int OP = obs_pitch(p.V);
   if (tid == 0) any_term = 0;
   init_luts(lut, tid);
   STAMP(1);
@@ -768,7 +774,7 @@ int dcd_mg_step(DcdMg* h, const int64_t* actions, int32_t flags, const DcdStepOu
   if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) { e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1]; h->ev_used += 2; }
   const int epb = step_epb(h->p.B);
   const dim3 grid((h->p.B + epb - 1) / epb);
-#define DCD_LAUNCH_STEP(EPB_, RR_) hipExtLaunchKernelGGL((mg_step_kernel<false, EPB_, RR_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, h->p, a)
+#define DCD_LAUNCH_STEP(EPB_, RR_) hipExtLaunchKernelGGL((mg_step_kernel<false, EPB_, RR_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, (const uint8_t*)h->rec, (const uint32_t*)h->seed, actions, h->p.B, h->p, a)
   const bool rr = (flags & DCD_STEP_RESET_RANDOM) != 0;
   if (epb == 16) { if (rr) DCD_LAUNCH_STEP(16, true); else DCD_LAUNCH_STEP(16, false); }
   else if (epb == 32) { if (rr) DCD_LAUNCH_STEP(32, true); else DCD_LAUNCH_STEP(32, false); }
@@ -822,7 +828,7 @@ int dcd_mg_step_random(DcdMg* h, uint32_t action_seed, uint32_t t0, int32_t K, i
   if (out) a.out = *out;
   const int epb = step_epb(h->p.B);
   const dim3 grid((h->p.B + epb - 1) / epb);
-#define DCD_LAUNCH_STEP(EPB_, RR_) hipLaunchKernelGGL((mg_step_kernel<true, EPB_, RR_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, h->p, a)
+#define DCD_LAUNCH_STEP(EPB_, RR_) hipLaunchKernelGGL((mg_step_kernel<true, EPB_, RR_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, (const uint8_t*)h->rec, (const uint32_t*)h->seed, (const int64_t*)nullptr, h->p.B, h->p, a)
   const bool rr = (flags & DCD_STEP_RESET_RANDOM) != 0;
   if (epb == 16) { if (rr) DCD_LAUNCH_STEP(16, true); else DCD_LAUNCH_STEP(16, false); }
   else if (epb == 32) { if (rr) DCD_LAUNCH_STEP(32, true); else DCD_LAUNCH_STEP(32, false); }
