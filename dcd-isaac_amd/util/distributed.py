@@ -19,7 +19,8 @@ def init(backend=None, device=None):
     if world == 1 or dist.is_initialized():
         return world
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    # DCD_DIST_BACKEND=gloo: rehearsal with several ranks on ONE GPU (RCCL refuses two ranks per device)
+    backend = backend or os.environ.get("DCD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
     dist.init_process_group(backend, **kw)
     return world

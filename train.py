@@ -33,7 +33,7 @@ def main():
     os.environ["OMP_NUM_THREADS"] = "1"
     args = parser.parse_args()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device(args.device or f"cuda:{local_rank}")
+    device = torch.device(args.device or f"cuda:{local_rank % max(torch.cuda.device_count(), 1)}")
     torch.cuda.set_device(device)
     world = D.init(device=device)
     rank = D.rank()
