@@ -52,7 +52,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-work budget of the cpu_baseline leg")
-    ap.add_argument("--sweep", action="store_true", help="also time dcd_mg_step alone at large B (roofline sweep)")
+    ap.add_argument("--sweep", dest="sweep", action="store_true", default=True,
+                    help="also time dcd_mg_step alone at B = 65 536 and 1 048 576, where it is HBM-bound (default: on, rank 0, N=1)")
+    ap.add_argument("--no-sweep", dest="sweep", action="store_false")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a shared GPU)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the end-to-end PAIRED leg (policy nets + PPO in the loop)")
     ap.add_argument("--train-updates", type=int, default=2, help="timed AdversarialRunner.run() calls of the end-to-end leg")
@@ -359,7 +361,7 @@ def main():
         n_recs = [int(a["scorer"].n_recs.item()) for a in ps.agents]
         episodes = [int(a["n_eps"].sum().item()) for a in ps.agents]
         kernel_s = step_kernel_profile(ps) if rank == 0 else None
-        sweep = sweep_large_b(device) if (args.sweep and rank == 0) else None
+        sweep = sweep_large_b(device) if (args.sweep and rank == 0 and world == 1) else None
 
     if rank == 0:
         total_steps = ps.steps_per_pass() * world * args.steps
@@ -384,7 +386,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "mg_step_kernel<false,16,false>",
                          "algorithmic_bytes_per_launch": algo, "avg_launch_us": kernel_s * 1e6,
-                         "note": "B=4096 moves 1.76 MB per launch: latency-bound, see DESIGN.md; --sweep adds large-B"},
+                         "note": "B=4096 moves 1.76 MB per launch: latency-bound (DESIGN.md §3); roofline_large_b: the same kernel where it is HBM-bound"},
         }
         if sweep is not None:
             line["roofline_large_b"] = sweep
