@@ -288,7 +288,8 @@ def end_to_end_leg(B, T, device, updates):
             "S_train_sps_reference_formula": B * T / dt,                    # train.py:184 counts one student rollout per update
             "S_train_true_env_steps_per_s": (2 * B * T + B * 27) / dt, "seconds_per_update": dt, "updates_timed": updates,
             "what": "AdversarialRunner.run(), PAIRED, LSTM-256 students (433 953 params) + recurrent teacher (22 502 732 params), "
-                    "PPO 5 epochs x 1 minibatch, fp32, eager PyTorch-ROCm"}
+                    "PPO 5 epochs x 1 minibatch, fp32; student rollouts: fused HIP policy step + env step replayed as HIP graphs; "
+                    "PPO: PyTorch-ROCm with the masked LSTM as one autograd node over HIP pointwise kernels"}
 
 
 def main():
