@@ -210,3 +210,37 @@ def test_every_shipped_multigrid_config_trains(name, flags):
     if args.use_plr and args.level_replay_prob > 0:
         assert len(runner.level_store) > 0
     venv.close()
+
+
+def test_graph_replayed_rollouts_equal_eager_rollouts(monkeypatch):
+    """Student rollouts on the fused policy path are captured as HIP graphs and replayed (DCD_HIP_GRAPHS=1, default).
+    Same seeds, graphs off vs on: every storage tensor bit-identical after each of four consecutive rollouts (the
+    graph path runs eager once, captures on the second call, then only replays; the Philox counter base lives on the
+    device so that replays draw fresh numbers), also across an optimiser step in between."""
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DCD_HIP_GRAPHS", mode)
+        args = make_args(ued_algo="paired", num_steps=40)
+        runner, venv = build(args)
+        assert runner.use_hip_graphs == (mode == "1")
+        agent, teacher = runner.agents["agent"], runner.agents["adversary_env"]
+        runner._teacher_rollout(teacher, runner.adversary_env_rollout_steps)
+        snaps = []
+        for k in range(4):
+            runner._student_rollout(agent, 40, False, None, {})
+            st = agent.storage
+            snaps.append({n: getattr(st, n).clone() for n in ("actions", "action_log_probs", "action_log_dist", "value_preds",
+                                                              "rewards", "masks", "bad_masks", "recurrent_hidden_states", "ep_ret")}
+                         | {"image": st.obs["image"].clone(), "direction": st.obs["direction"].clone()})
+            if k == 1:                                               # the policy changes between rollouts, as in training
+                with torch.no_grad():
+                    for p in agent.algo.actor_critic.parameters():
+                        p.add_(0.01 * torch.sin(torch.arange(p.numel(), device=p.device, dtype=p.dtype)).view_as(p))
+        results[mode] = snaps
+        assert runner._fused_actor(agent) is not None
+        venv.close()
+    for k, (a, b) in enumerate(zip(results["0"], results["1"])):
+        for n in a:
+            assert torch.equal(a[n], b[n]), (k, n)
+    assert not torch.equal(results["1"][0]["actions"], results["1"][1]["actions"])     # fresh draws per rollout
+    assert not torch.equal(results["1"][2]["actions"], results["1"][3]["actions"])
