@@ -489,9 +489,17 @@ class LevelSampler:
         elif transform in ("rank", "match_rank"):
             base = scores if transform == "rank" else np.array([(1 - s) * s for s in scores])
             temp = np.flip(base.argsort())
-            ranks = np.empty_like(temp)
-            ranks[temp] = np.arange(len(temp)) + 1
-            weights = 1 / ranks ** (1.0 / temperature)
+            # weights = 1 / ranks ** (1 / temperature) with ranks[temp] = 1..N (:765-769): the value for rank k is the
+            # same elementwise expression whatever the order, so it is tabulated once per (N, temperature) and scattered
+            key = (len(temp), temperature)
+            tab = self._rank_weight_tables.get(key) if hasattr(self, "_rank_weight_tables") else None
+            if tab is None:
+                tab = 1 / (np.arange(len(temp)) + 1) ** (1.0 / temperature)
+                if not hasattr(self, "_rank_weight_tables"):
+                    self._rank_weight_tables = {}
+                self._rank_weight_tables[key] = tab
+            weights = np.empty(len(temp), dtype=tab.dtype)
+            weights[temp] = tab
         elif transform == "power":
             eps = 0 if self.staleness_coef > 0 else 1e-3
             weights = (np.array(scores).clip(0) + eps) ** (1.0 / temperature)
