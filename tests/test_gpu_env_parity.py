@@ -116,3 +116,14 @@ def test_error_latch():
         e.raise_errors()
     with pytest.raises(dcd_hip.DcdHipError):
         e.step(torch.zeros(8, dtype=torch.int64))      # CPU tensor must be refused, not copied
+
+
+@pytest.mark.parametrize("B,seed", [(16384 + 37, 11), (32768 + 5, 12)])
+def test_wide_workgroup_variants_match_oracle(B, seed):
+    """The step / level kernels pick 32 or 64 envs per workgroup from B >= 16 384 / 32 768 (the HBM-bound regime of the
+    roofline sweep); the randomised driver at those batch sizes, with a ragged last workgroup."""
+    from tests.hip_adapter import HipMg
+    cfg = dict(num_envs=B, engine_seed=seed, env_index_base=5 * seed, n_clutter=25, choose_goal_last=1, max_episode_steps=40)
+    x, y = orc.OracleMg(**cfg), HipMg(**cfg)
+    mg_diff.compare_state(x, y, "after create")
+    mg_diff.drive(x, y, np.random.default_rng(seed), n_calls=9, steps_per_call=12, exotic=True, check_every=3)
