@@ -206,9 +206,19 @@ class RNN(nn.Module):
             return h, (h, c)
         N = h.size(0)
         T = x.size(0) // N
-        xp = torch.addmm(r.bias_ih_l0 + r.bias_hh_l0, x, r.weight_ih_l0.t()).view(T, N, 4 * H)
-        if x.is_cuda and _fused_lstm_enabled():
-            out, hT, cT = MaskedLSTMSequence.apply(xp, h, c, masks.view(T, N), r.weight_hh_l0)
+        xp = torch.addmm(r.bias_ih_l0 + r.bias_hh_l0, x, r.weight_ih_l0.t())
+        return self.forward_projected(xp, hxs, masks)
+
+    def forward_projected(self, xp, hxs, masks):
+        """The sequence recurrence on an input projection `xp` [T*N, 4H] = x @ W_ih^T + b_ih + b_hh that the caller
+        has already formed (MultigridNetwork forms the teacher's incrementally, models/multigrid_models.py)."""
+        H = self._hidden_size
+        h, c = hxs
+        N = h.size(0)
+        T = xp.size(0) // N
+        xp = xp.view(T, N, 4 * H)
+        if xp.is_cuda and _fused_lstm_enabled():
+            out, hT, cT = MaskedLSTMSequence.apply(xp, h, c, masks.view(T, N), self.rnn.weight_hh_l0)
             return out.view(T * N, H), (hT, cT)
         return self._lstm_cuda_unfused(xp, h, c, masks, T, N)
 

@@ -58,10 +58,87 @@ class MultigridNetwork(DeviceAwareModule):
     def forward(self, inputs, rnn_hxs, masks):
         raise NotImplementedError
 
+    # ---- incremental input projection for grid-building sequences (the teacher's PPO batch) ----------------
+    # A constructive teacher places ONE object per step, so consecutive observations differ in one or two cells and
+    # the conv features F_t (F x P values, 21 632 for the 15 x 15 teacher) differ from F_{t-1} in at most 9 of the P
+    # output positions.  The LSTM's input projection is linear in the features, hence
+    #     F_t W^T = F_{t-1} W^T + (F_t - F_{t-1}) W^T ,
+    # and the right-hand term needs only the changed positions: per position p a [rows_p, F] x [F, 4H] product.  The
+    # batch's projection becomes one dense GEMM for t = 0 plus ~5 % of the dense FLOPs, accumulated over time with a
+    # cumsum; autograd differentiates the same composition (the backward of the cumsum is the reverse cumsum of the
+    # incoming gradient, which turns the two backward GEMMs sparse in the same way).  Exact algebra — results equal the
+    # dense path up to fp32 summation order (tests/test_gpu_policy.py); falls back to the dense path when more than
+    # `INCREMENTAL_MAX_DENSITY` of the (t, n, p) triples changed.
+    INCREMENTAL_MAX_DENSITY = 0.3
+
+    def _incremental_eligible(self, image, n_state):
+        import os
+        return (image is not None and image.is_cuda and self.rnn is not None and self.rnn.is_lstm
+                and image.dim() == 4 and image.size(0) >= 4 * n_state and image.size(0) % n_state == 0
+                and self.image_embedding_size >= 4096 and self.image_conv[0].kernel_size == (3, 3)
+                and os.environ.get("DCD_INCREMENTAL_PROJECTION", "1") != "0")
+
+    def _incremental_projection(self, image, N):
+        """xp_conv [T*N, 4H] = relu(conv(image)).flatten(1) @ W_ih[:, :F*P]^T for a time-major [T*N, 3, S, S] batch of N
+        sequences, or None when the sequences are not sparse enough."""
+        import torch.nn.functional as Fn
+        conv = self.image_conv[0]
+        lstm = self.rnn.rnn
+        TN, C, S, _ = image.shape
+        T, O, F = TN // N, S - 2, conv.out_channels
+        P, G = O * O, lstm.weight_ih_l0.size(0)
+        img = image.view(T, N, C, S, S)
+        with torch.no_grad():
+            changed = (img[1:] != img[:-1]).any(dim=2)                                      # [T-1,N,S,S]
+            dirty = Fn.max_pool2d(changed.float().view(-1, 1, S, S), 3, 1).view(T - 1, N, O, O) > 0
+            tt, nn_, oy, ox = dirty.nonzero(as_tuple=True)
+            M = tt.numel()
+            if M > self.INCREMENTAL_MAX_DENSITY * (T - 1) * N * P:
+                return None
+            p = oy * O + ox
+            order = torch.argsort(p, stable=True)                                           # group the triples by position
+            counts = torch.bincount(p, minlength=P).cpu().tolist()                          # (one host sync)
+            tt, nn_, oy, ox = tt[order], nn_[order], oy[order], ox[order]
+            row_t, row_prev = (tt + 1) * N + nn_, tt * N + nn_
+            k = torch.arange(3, device=image.device)
+            offs = (torch.arange(C, device=image.device).view(C, 1, 1) * S * S + k.view(1, 3, 1) * S + k.view(1, 1, 3)).reshape(-1)
+            col = (oy * S + ox).unsqueeze(1) + offs.unsqueeze(0)                            # [M, 27]: the 3x3xC window of each triple
+        flat = image.reshape(TN, C * S * S)
+        wc, w_ih = conv.weight.view(F, -1), lstm.weight_ih_l0
+        wf = w_ih[:, :F * P]
+        xp = torch.zeros((TN, G), device=image.device, dtype=image.dtype)
+        xp[:N] = self.image_conv(img[0]) @ wf.t()                                            # t = 0: dense
+        if M:
+            act = lambda rows: torch.relu(torch.addmm(conv.bias, flat[rows.unsqueeze(1), col], wc.t()))
+            delta = act(row_t) - act(row_prev)                                               # [M, F] feature change per triple
+            wperm = wf.view(G, F, P).permute(2, 1, 0).contiguous()                           # [P, F, 4H]
+            s = 0
+            for q, c in enumerate(counts):                                                   # rows of one position are distinct
+                if c:                                                                        # (t, n): the scatter-add is deterministic
+                    xp.index_add_(0, row_t[s:s + c], delta[s:s + c] @ wperm[q])
+                    s += c
+        return xp.view(T, N, G).cumsum(0).view(TN, G)
+
     def _forward_base(self, inputs, rnn_hxs, masks):
         scalar = inputs.get("direction")
         if scalar is None:
             scalar = inputs.get("time_step")
+        image = inputs.get("image")
+        n_state = rnn_hxs[0].size(0) if isinstance(rnn_hxs, (tuple, list)) else (rnn_hxs.size(0) if rnn_hxs is not None else 0)
+        if self.rnn is not None and n_state and self._incremental_eligible(image, n_state):
+            xp = self._incremental_projection(image, n_state)
+            if xp is not None:
+                lstm = self.rnn.rnn
+                rest = []
+                if self.scalar_embed is not None:
+                    rest.append(self.scalar_embed(one_hot(self.scalar_dim, scalar).to(self.device)))
+                z = inputs.get("random_z")
+                if z is not None:
+                    rest.append(z)
+                xp = xp + (lstm.bias_ih_l0 + lstm.bias_hh_l0)
+                if rest:
+                    xp = torch.addmm(xp, torch.cat(rest, dim=-1), lstm.weight_ih_l0[:, self.image_embedding_size:].t())
+                return self.rnn.forward_projected(xp, rnn_hxs, masks)
         parts = [self.image_conv(inputs.get("image"))]
         if self.scalar_embed is not None:
             parts.append(self.scalar_embed(one_hot(self.scalar_dim, scalar).to(self.device)))

@@ -201,3 +201,43 @@ def test_fused_lstm_sequence_without_final_state_grads(monkeypatch):
         outs.append([y.detach()] + [p.grad.clone() for p in rnn.parameters()])
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1e-6) + 1e-6
+
+
+# ---- incremental input projection of the teacher's PPO batch --------------------------------------------
+def test_incremental_teacher_projection_matches_dense_path(monkeypatch):
+    """MultigridNetwork._incremental_projection (dense GEMM at t = 0 + per-position products of the changed conv
+    features, cumsum over time) vs the dense conv -> Linear path on a real 27-step teacher rollout: same values,
+    log-probs, entropy and parameter gradients up to fp32 summation order (the 21 632-term dot products of the dense
+    path and the incremental sums round differently: 1e-4 relative to each tensor's scale)."""
+    from tests.test_gpu_runner import build, make_args
+    args = make_args(ued_algo="paired", num_processes=48)
+    runner, venv = build(args)
+    teacher = runner.agents["adversary_env"]
+    runner._teacher_rollout(teacher, runner.adversary_env_rollout_steps)
+    st, net = teacher.storage, teacher.algo.actor_critic
+    T, N = st.actions.shape[:2]
+    obs = {k: v[:-1].reshape(T * N, *v.shape[2:]) for k, v in st.obs.items()}
+    hxs = st.get_recurrent_hidden_state(0)
+    masks, actions = st.masks[:-1].reshape(T * N, 1), st.actions.reshape(T * N, 1)
+    assert net._incremental_eligible(obs["image"], N)
+    w = torch.randn(T * N, 1, device=DEV)
+
+    def run(flag):
+        monkeypatch.setenv("DCD_INCREMENTAL_PROJECTION", flag)
+        net.zero_grad()
+        v, lp, ent, _ = net.evaluate_actions(obs, hxs, masks, actions)
+        ((v * w).sum() + (lp * w).sum() + ent).backward()
+        return [v.detach(), lp.detach(), ent.detach()] + [p.grad.clone() for p in net.parameters()]
+
+    dense, inc = run("0"), run("1")
+    names = ["value", "log_prob", "entropy"] + [n for n, _ in net.named_parameters()]
+    for n, a, b in zip(names, dense, inc):
+        scale = max(a.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() <= 1e-4 * scale + 1e-6, (n, (a - b).abs().max().item(), scale)
+    # the path really ran: the projection is formed and is sparse on a constructive teacher's rollout
+    xp = net._incremental_projection(obs["image"], N)
+    assert xp is not None and xp.shape == (T * N, 1024)
+    # a batch whose frames are unrelated is not sparse: dense fallback
+    noise = torch.rand_like(obs["image"])
+    assert net._incremental_projection(noise, N) is None
+    venv.close()
