@@ -111,12 +111,13 @@ class MultigridNetwork(DeviceAwareModule):
         if M:
             act = lambda rows: torch.relu(torch.addmm(conv.bias, flat[rows.unsqueeze(1), col], wc.t()))
             delta = act(row_t) - act(row_prev)                                               # [M, F] feature change per triple
-            wperm = wf.view(G, F, P).permute(2, 1, 0).contiguous()                           # [P, F, 4H]
-            s = 0
+            # unbind / split (ONE backward node each, which stacks / concatenates the pieces' grads): indexing wperm[q]
+            # and delta[a:b] inside the loop would make every iteration's backward materialise a full-size zero tensor
+            wparts = wf.view(G, F, P).permute(2, 1, 0).contiguous().unbind(0)               # P x [F, 4H]
+            dparts, rparts = delta.split(counts), row_t.split(counts)
             for q, c in enumerate(counts):                                                   # rows of one position are distinct
                 if c:                                                                        # (t, n): the scatter-add is deterministic
-                    xp.index_add_(0, row_t[s:s + c], delta[s:s + c] @ wperm[q])
-                    s += c
+                    xp.index_add_(0, rparts[q], dparts[q] @ wparts[q])
         return xp.view(T, N, G).cumsum(0).view(TN, G)
 
     def _forward_base(self, inputs, rnn_hxs, masks):
