@@ -41,6 +41,56 @@ def apply_init_(modules, gain=None):
                 nn.init.constant_(m.bias, 0)
 
 
+def matmul_tn(a, b):
+    """a^T @ b for tall operands ([R, m]^T @ [R, k], R ~ 10^6): the weight-gradient shape of every layer in the PPO
+    batch.  rocBLAS runs it as one skinny GEMM with a 10^6-long reduction (1.96 ms for m = 32, k = 256; 5.6 ms for the
+    conv's m = 16, k = 27 over 9.4M rows); as a batched GEMM over S slices of the rows followed by a sum over the S
+    partial products (split-K) the same contraction takes 0.25 / 0.28 ms (tools/splitk_probe.py).  Same fp32 products,
+    partial sums added in a different order."""
+    R = a.size(0)
+    if not a.is_cuda or R < 65536:
+        return a.t() @ b
+    S = 256
+    while S > 1 and (R % S or R // S < 256):
+        S //= 2
+    if S == 1:
+        return a.t() @ b
+    return torch.bmm(a.reshape(S, R // S, a.size(1)).transpose(1, 2), b.reshape(S, R // S, b.size(1))).sum(0)
+
+
+class _LinearSplitK(torch.autograd.Function):
+    """y = x @ w^T + b whose weight gradient goes through matmul_tn."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.addmm(b, x, w.t()) if b is not None else x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = matmul_tn(g, x) if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    """F.linear for 2-D inputs; on the PPO batch (>= 65 536 rows on the GPU) with the split-K weight gradient."""
+    if x.is_cuda and x.dim() == 2 and x.size(0) >= 65536 and torch.is_grad_enabled():
+        return _LinearSplitK.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters, same state-dict names) routed through `linear`."""
+
+    def forward(self, x):
+        return linear(x, self.weight, self.bias)
+
+
 class DeviceAwareModule(nn.Module):
     @property
     def device(self):
@@ -82,14 +132,13 @@ def _valid_conv_gemm(self, x):
     O, _, kh, kw = self.weight.shape
     oh, ow = H - kh + 1, W - kw + 1
     K = C * kh * kw
-    w_t = self.weight.view(O, K).t()
     outs = []
     for s in range(0, N, 262144):                                  # bound the im2col workspace
         xs = x[s:s + 262144]
         n = xs.size(0)
         cols = torch.stack([xs[:, :, i:i + oh, j:j + ow] for i in range(kh) for j in range(kw)], dim=2)  # [n,C,kh*kw,oh,ow]
         a = cols.permute(0, 3, 4, 1, 2).reshape(n * oh * ow, K)      # rows: (image, out cell); cols: (c, ki, kj)
-        y = torch.addmm(self.bias, a, w_t) if self.bias is not None else a @ w_t
+        y = linear(a, self.weight.view(O, K), self.bias)
         outs.append(y.view(n, oh * ow, O).transpose(1, 2).reshape(n, O, oh, ow))
     return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
@@ -159,7 +208,7 @@ class MaskedLSTMSequence(torch.autograd.Function):
         m0 = masks[0].unsqueeze(1)
         d_h0 = dhm * m0 if ctx.needs_input_grad[1] else None
         d_c0 = dcf[0] * m0 if ctx.needs_input_grad[2] else None
-        d_w = dg.view(T * N, G).t() @ hm.view(T * N, H) if ctx.needs_input_grad[4] else None
+        d_w = matmul_tn(dg.view(T * N, G), hm.view(T * N, H)) if ctx.needs_input_grad[4] else None
         return dg, d_h0, d_c0, None, d_w
 
 
@@ -206,7 +255,7 @@ class RNN(nn.Module):
             return h, (h, c)
         N = h.size(0)
         T = x.size(0) // N
-        xp = torch.addmm(r.bias_ih_l0 + r.bias_hh_l0, x, r.weight_ih_l0.t())
+        xp = linear(x, r.weight_ih_l0, r.bias_ih_l0 + r.bias_hh_l0)
         return self.forward_projected(xp, hxs, masks)
 
     def forward_projected(self, xp, hxs, masks):
@@ -273,5 +322,5 @@ def one_hot(dim, inputs, device="cpu"):
 def make_fc_layers_with_hidden_sizes(sizes, input_size):
     layers = []
     for i in range(len(sizes) - 1):
-        layers += [init_tanh_(nn.Linear(input_size if i == 0 else sizes[0], sizes[i + 1])), nn.Tanh()]
+        layers += [init_tanh_(Linear(input_size if i == 0 else sizes[0], sizes[i + 1])), nn.Tanh()]
     return nn.Sequential(*layers)

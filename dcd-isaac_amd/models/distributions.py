@@ -17,7 +17,8 @@ class FixedCategorical(torch.distributions.Categorical):
 class Categorical(nn.Module):
     def __init__(self, num_inputs, num_outputs):
         super().__init__()
-        self.linear = nn.Linear(num_inputs, num_outputs)
+        from .common import Linear
+        self.linear = Linear(num_inputs, num_outputs)
         nn.init.orthogonal_(self.linear.weight.data, gain=0.01)
         nn.init.constant_(self.linear.bias.data, 0)
 

@@ -8,8 +8,8 @@ the reference so seeds and checkpoints are interchangeable.
 import torch
 import torch.nn as nn
 
-from .common import (Conv2d_tf, DeviceAwareModule, RNN, apply_init_, init_, make_fc_layers_with_hidden_sizes,
-                     one_hot)
+from .common import (Conv2d_tf, DeviceAwareModule, Linear, RNN, apply_init_, init_, linear,
+                     make_fc_layers_with_hidden_sizes, one_hot)
 from .distributions import Categorical
 
 
@@ -32,7 +32,7 @@ class MultigridNetwork(DeviceAwareModule):
             self.preprocessed_input_size += 2 * xy_dim
         self.scalar_embed, self.scalar_dim = None, scalar_dim
         if scalar_dim:
-            self.scalar_embed = nn.Linear(scalar_dim, scalar_fc)
+            self.scalar_embed = Linear(scalar_dim, scalar_fc)
             self.preprocessed_input_size += scalar_fc
         self.preprocessed_input_size += random_z_dim
         self.base_output_size = self.preprocessed_input_size
@@ -43,7 +43,7 @@ class MultigridNetwork(DeviceAwareModule):
         self.actor = nn.Sequential(make_fc_layers_with_hidden_sizes(actor_fc_layers, self.base_output_size),
                                    Categorical(actor_fc_layers[-1], action_space.n))
         self.critic = nn.Sequential(make_fc_layers_with_hidden_sizes(value_fc_layers, self.base_output_size),
-                                    init_(nn.Linear(value_fc_layers[-1], 1)))
+                                    init_(Linear(value_fc_layers[-1], 1)))
         apply_init_(self.modules())
         self.train()
 
@@ -138,7 +138,7 @@ class MultigridNetwork(DeviceAwareModule):
                     rest.append(z)
                 xp = xp + (lstm.bias_ih_l0 + lstm.bias_hh_l0)
                 if rest:
-                    xp = torch.addmm(xp, torch.cat(rest, dim=-1), lstm.weight_ih_l0[:, self.image_embedding_size:].t())
+                    xp = xp + linear(torch.cat(rest, dim=-1), lstm.weight_ih_l0[:, self.image_embedding_size:])
                 return self.rnn.forward_projected(xp, rnn_hxs, masks)
         parts = [self.image_conv(inputs.get("image"))]
         if self.scalar_embed is not None:
