@@ -80,6 +80,7 @@ class LevelSampler:
             self.partial_seed_max_scores_buffer = [{} for _ in range(num_actors)]
             self.partial_seed_steps_buffer = [{} for _ in range(num_actors)]
         self._scorer = None
+        self._state_version, self._weakest_memo = 0, None
         # (actor, seed index) pairs holding a partial score: after_update visits exactly these instead of scanning the
         # whole [num_actors, N] matrix (1 GB at 32 768 actors x 4000 seeds)
         self._partial_dirty = set()
@@ -142,6 +143,7 @@ class LevelSampler:
             self.partial_seed_scores[actor_index, seed_idx] = 0.0
             self.partial_seed_max_scores[actor_index, seed_idx] = float("-inf")
             self.partial_seed_steps[actor_index, seed_idx] = 0
+            self._state_version = getattr(self, "_state_version", 0) + 1
             self.unseen_seed_weights[seed_idx] = 0.0
             old = self.seed_scores[seed_idx]
             total = self.max_score_coef * merged_max + (1 - self.max_score_coef) * merged
@@ -158,7 +160,17 @@ class LevelSampler:
         if self._proportion_filled < 1.0:
             return self.working_seed_buffer_size
         if self.seed_buffer_priority == "replay_support":
-            return self.sample_weights().argmin()
+            # Inside update_with_records the weakest slot is memoised on a state version: a candidate level that is
+            # rejected (lower score than that slot) leaves scores / staleness / unseen flags untouched, so the next
+            # candidate sees the same weights — at 4096 envs an exploratory update tries 4096 candidates, and each
+            # sample_weights() is an argsort of the whole buffer.
+            memo = getattr(self, "_weakest_memo", None)
+            if memo is not None and memo[0] == self._state_version:
+                return memo[1]
+            idx = self.sample_weights().argmin()
+            if memo is not None:
+                self._weakest_memo = (self._state_version, idx)
+            return idx
         return self.seed_scores.argmin()
 
     def _partial_update_seed_score_buffer(self, actor_index, seed, score, num_steps, done=False):
@@ -171,6 +183,7 @@ class LevelSampler:
         if done:
             seed_idx = self._next_buffer_index
             if self.seed_scores[seed_idx] <= merged or self.unseen_seed_weights[seed_idx] > 0:
+                self._state_version = getattr(self, "_state_version", 0) + 1
                 self.unseen_seed_weights[seed_idx] = 0.0
                 self.working_seed_set.discard(self.seeds[seed_idx])
                 self.working_seed_set.add(seed)
@@ -258,6 +271,14 @@ class LevelSampler:
         steps_l, means, maxes = recs["num_steps"].tolist(), recs["mean_score"].tolist(), recs["max_score"].tolist()
         rsums = recs["reward_sum"].tolist() if grounded else None
         staging = self.staging_seed_set if self.sample_full_distribution else ()
+        self._state_version = getattr(self, "_state_version", 0) + 1
+        self._weakest_memo = (-1, None)                              # memoisation on for the duration of this loop only:
+        try:                                                         # outside it callers may edit the arrays directly
+            self._consume(actors, seeds, flags_l, steps_l, means, maxes, rsums, recs, values, actor_offset, grounded, positive, staging)
+        finally:
+            self._weakest_memo = None
+
+    def _consume(self, actors, seeds, flags_l, steps_l, means, maxes, rsums, recs, values, actor_offset, grounded, positive, staging):
         for k in range(len(actors)):
             actor = actors[k] + actor_offset
             seed, flags, num_steps = seeds[k], flags_l[k], steps_l[k]
@@ -314,6 +335,7 @@ class LevelSampler:
 
     # ---- sampling (reference :601-750) -----------------------------------------------------------
     def _update_staleness(self, selected_idx):
+        self._state_version = getattr(self, "_state_version", 0) + 1
         if self.staleness_coef > 0:
             self.seed_staleness = self.seed_staleness + 1
             self.seed_staleness[selected_idx] = 0
