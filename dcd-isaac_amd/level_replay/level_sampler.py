@@ -415,17 +415,23 @@ class LevelSampler:
             ws = ws * unseen_keep
             ws /= np.sum(ws)
         c, N = self.staleness_coef, len(self.seeds)
+        w_scores = (1 - c) * ws if c > 0 else ws                     # constant across the batch of draws
+        # 'power' with temperature 1 and eps 0 (staleness_coef > 0): (clip(s, 0) + 0) ** 1.0 is s itself, bit for bit
+        plain_staleness = self.staleness_transform == "power" and self.staleness_temperature == 1.0
         out = []
         for _ in range(n):
             if c > 0:
-                sw = self._score_transform(self.staleness_transform, self.staleness_temperature, self.seed_staleness)
-                sw = sw * unseen_keep
+                if plain_staleness and self.seed_staleness.min() >= 0:
+                    sw = self.seed_staleness * unseen_keep
+                else:
+                    sw = self._score_transform(self.staleness_transform, self.staleness_temperature, self.seed_staleness)
+                    sw = sw * unseen_keep
                 z = np.sum(sw)
                 if z > 0:
                     sw /= z
                 else:
                     sw = 1.0 / len(sw) * unseen_keep
-                w = (1 - c) * ws + c * sw
+                w = w_scores + c * sw
             else:
                 w = ws
             total = np.sum(w)
