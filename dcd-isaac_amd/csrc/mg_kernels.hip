@@ -398,21 +398,22 @@ __device__ __forceinline__ void emit_grid(const uint8_t* lds, const Luts& lut, u
 }
 
 template <int OP, int EPB>
-__global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(Params p, LevelArgs a) {
+__global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uint8_t* __restrict__ rec_in, const int32_t* __restrict__ idx_in,
+                                                                      int n_rows_in, Params p, LevelArgs a) {   // leading scalars: kernarg preload
   constexpr int NT = Threads<EPB>::value;
   __shared__ __attribute__((aligned(16))) uint8_t lds[EPB * LP];
   __shared__ int env_of[EPB];
   __shared__ uint32_t zctr[EPB];                  // per-row rng counter at which this call's random_z starts
   __shared__ Luts lut;
   const int tid = threadIdx.x, row0 = blockIdx.x * EPB;
-  const int n = min(EPB, a.n_rows - row0), row = row0 + tid;
+  const int n = min(EPB, n_rows_in - row0), row = row0 + tid;
+  if (tid < EPB) env_of[tid] = (tid < n) ? (idx_in ? idx_in[row] : row) : -1;
   const int S = p.S;
-  if (tid < EPB) env_of[tid] = (tid < n) ? (a.idx ? a.idx[row] : row) : -1;
   init_luts(lut, tid);
   __syncthreads();
   {
     StageBuf<EPB, NT> sb;
-    stage_load<EPB, NT>(sb, a.rec, [&](int r) { return env_of[r]; }, n, tid);
+    stage_load<EPB, NT>(sb, rec_in, [&](int r) { return env_of[r]; }, n, tid);
     stage_commit<EPB, NT>(sb, lds, n, tid);
   }
   __syncthreads();
@@ -608,9 +609,9 @@ template <int OP> static int launch_level(DcdMg* h, const LevelArgs& a, void* st
   if (a.n_rows <= 0) return 0;
   const int epb = step_epb(a.n_rows);
   const dim3 grid((a.n_rows + epb - 1) / epb);
-  if (epb == 16) hipLaunchKernelGGL((mg_level_kernel<OP, 16>), grid, dim3(Threads<16>::value), 0, (hipStream_t)stream, h->p, a);
-  else if (epb == 32) hipLaunchKernelGGL((mg_level_kernel<OP, 32>), grid, dim3(Threads<32>::value), 0, (hipStream_t)stream, h->p, a);
-  else hipLaunchKernelGGL((mg_level_kernel<OP, 64>), grid, dim3(Threads<64>::value), 0, (hipStream_t)stream, h->p, a);
+  if (epb == 16) hipLaunchKernelGGL((mg_level_kernel<OP, 16>), grid, dim3(Threads<16>::value), 0, (hipStream_t)stream, (const uint8_t*)a.rec, a.idx, a.n_rows, h->p, a);
+  else if (epb == 32) hipLaunchKernelGGL((mg_level_kernel<OP, 32>), grid, dim3(Threads<32>::value), 0, (hipStream_t)stream, (const uint8_t*)a.rec, a.idx, a.n_rows, h->p, a);
+  else hipLaunchKernelGGL((mg_level_kernel<OP, 64>), grid, dim3(Threads<64>::value), 0, (hipStream_t)stream, (const uint8_t*)a.rec, a.idx, a.n_rows, h->p, a);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -241,3 +241,28 @@ def test_incremental_teacher_projection_matches_dense_path(monkeypatch):
     noise = torch.rand_like(obs["image"])
     assert net._incremental_projection(noise, N) is None
     venv.close()
+
+
+def test_split_k_linear_matches_plain_linear():
+    """models.common.linear on a PPO-sized batch (weight gradient as a batched GEMM over row slices + sum) vs
+    F.linear: same output, input / weight / bias gradients up to fp32 summation order."""
+    import torch.nn.functional as F
+    from models.common import linear, matmul_tn
+    torch.manual_seed(0)
+    for R, k, m in [(65536, 256, 32), (131072 + 4096, 27, 16), (70000, 32, 7)]:
+        x = torch.randn(R, k, device=DEV, requires_grad=True)
+        w = torch.randn(m, k, device=DEV, requires_grad=True)
+        b = torch.randn(m, device=DEV, requires_grad=True)
+        g = torch.randn(R, m, device=DEV)
+        outs = []
+        for fn in (F.linear, linear):
+            for t in (x, w, b):
+                t.grad = None
+            y = fn(x, w, b)
+            y.backward(g)
+            outs.append([y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone()])
+        for a, c in zip(*outs):
+            assert (a - c).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1.0)
+        a2, b2 = torch.randn(R, m, device=DEV), torch.randn(R, k, device=DEV)
+        ref = a2.t() @ b2
+        assert (matmul_tn(a2, b2) - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
