@@ -36,7 +36,7 @@ class Evaluator:
         self._fused = {}
         self.venv = {}
         for name in self.env_names:
-            if not name.startswith("MultiGrid"):
+            if not (name.startswith("MultiGrid") or name.startswith("MiniGrid")):           # eval.py:208
                 raise ValueError(f"{name}: only the MultiGrid evaluation families are built (SURVEY §8f-2)")
             make_fn = [lambda n=name: gym_make(n)] * num_processes
             self.venv[name] = HipAdversarialVecEnv(make_fn, adversary=False, is_eval=True, device=device)

@@ -8,7 +8,7 @@ from oracle import orc
 from tests import mg_diff
 from tests.hostsim import sim
 
-CASES = [("MultiGrid-LargeCorridor-v0", 32, 6), ("MultiGrid-PerfectMazeMedium-v0", 32, 6),
+CASES = [("MultiGrid-LargeCorridor-v0", 32, 6), ("MultiGrid-PerfectMazeMedium-v0", 32, 6), ("MiniGrid-FourRooms-v0", 32, 8),
          ("MultiGrid-PerfectMazeLarge-v0", 64, 3), ("MultiGrid-PerfectMazeXL-v0", 128, 2)]
 
 
@@ -47,7 +47,7 @@ def test_wide_pitch_logic_matches_oracle(name, pitch, B):
     cfg = dict(num_envs=B, **descs[0].engine_config())
     cfg["max_episode_steps"] = 150                                  # time limits fire inside the test (terminal obs)
     x, y = orc.OracleMg(**cfg), sim.host_sim_class(pitch)(**cfg)
-    rollout_matches(x, y, enc, 400, np.random.default_rng(pitch))
+    rollout_matches(x, y, enc, 397, np.random.default_rng(pitch))
 
 
 def test_default_pitch_refuses_large_grids():
@@ -97,3 +97,54 @@ def test_cluttered_levels():
         inner = enc[1:-1, 1:-1, 0]
         assert (inner == (9 if lava else 2)).sum() == n_clutter and (inner == 8).sum() == 1 and (inner == 10).sum() == 1
         assert not np.array_equal(enc, d.level_encoding())
+
+
+def _reachable(enc):
+    free = ~np.isin(enc[..., 0], (2, 9))                              # not wall, not lava
+    seen = np.zeros_like(free)
+    stack = [tuple(np.argwhere(enc[..., 0] == 10)[0])]
+    while stack:
+        x, y = stack.pop()
+        if seen[x, y] or not free[x, y]:
+            continue
+        seen[x, y] = True
+        stack += [(x + 1, y), (x - 1, y), (x, y + 1), (x, y - 1)]
+    gx, gy = np.argwhere(enc[..., 0] == 8)[0]
+    return bool(seen[gx, gy])
+
+
+@pytest.mark.parametrize("name,size,n,obst", [("MiniGrid-LavaCrossingS9N1-v0", 9, 1, 9), ("MiniGrid-LavaCrossingS11N5-v0", 11, 5, 9),
+                                              ("MiniGrid-SimpleCrossingS9N3-v0", 9, 3, 2), ("MiniGrid-SimpleCrossingS11N5-v0", 11, 5, 2)])
+def test_crossing_levels(name, size, n, obst):
+    """crossing.py:41-101: `n` full rivers on even rows / columns, one opening per river along a monotone path, so the
+    goal in the far corner is always reachable from the agent in (1,1) without touching an obstacle."""
+    import envs.multigrid  # noqa: F401
+    from envs.registration import make
+    d = make(name)
+    d.seed(size * 10 + n)
+    assert d.size == size and d.max_steps == 4 * size * size and not d.see_through_walls and d.agent_view_size == 5
+    levels = [d.level_encoding() for _ in range(20)]
+    assert len({l.tobytes() for l in levels}) > 5
+    for enc in levels:
+        assert tuple(enc[1, 1]) == (10, 0, 0) and tuple(enc[size - 2, size - 2]) == (8, 1, 0)
+        inner = enc[1:-1, 1:-1, 0]
+        rows = [j for j in range(size - 2) if (inner[:, j] == obst).sum() >= size - 3]      # a river minus its one opening
+        cols = [i for i in range(size - 2) if (inner[i, :] == obst).sum() >= size - 3]
+        assert len(rows) + len(cols) == n and all((k + 1) % 2 == 0 for k in rows + cols)
+        assert _reachable(enc)
+
+
+def test_four_rooms_levels():
+    import envs.multigrid  # noqa: F401
+    from envs.registration import make
+    d = make("MiniGrid-FourRooms-v0")
+    d.seed(4)
+    assert d.size == 19 and d.max_steps == 100
+    dirs = set()
+    for _ in range(20):
+        enc = d.level_encoding()
+        t = enc[..., 0]
+        assert (t[9, 1:18] == 2).sum() == 15 and (t[1:18, 9] == 2).sum() == 15     # a wall cross with 2 + 2 gaps
+        assert (t == 8).sum() == 1 and (t == 10).sum() == 1 and _reachable(enc)
+        dirs.add(int(enc[..., 2][t == 10][0]))
+    assert len(dirs) > 1                                              # random start direction (fourrooms.py:72-76)
