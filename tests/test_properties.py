@@ -8,7 +8,7 @@ from tests import mg_diff
 from tests.hostsim import sim
 
 
-@settings(max_examples=25, deadline=None)
+@settings(max_examples=25, deadline=None, derandomize=True)
 @given(seed=st.integers(0, 2 ** 31 - 1), size=st.sampled_from([6, 10, 15]), view=st.sampled_from([3, 5, 7]),
        n_clutter=st.integers(0, 60), goal_last=st.booleans())
 def test_teacher_then_student_invariants(seed, size, view, n_clutter, goal_last):
@@ -27,6 +27,15 @@ def test_teacher_then_student_invariants(seed, size, view, n_clutter, goal_last)
         ox, oy = x.step_adversary(loc), y.step_adversary(loc)
     mg_diff.assert_same(ox, oy, "teacher")
     assert ox["done"].all()
+    ex, ey = x.poll_errors(), y.poll_errors()
+    assert ex == ey
+    if ex[0] & 16:
+        # n_clutter >= the number of interior cells and the teacher filled them all: the agent's random fallback finds no
+        # free cell — the reference raises RetriesExceededError there (multigrid.py:597-599), both engines latch
+        # DCD_ERR_NO_FREE_CELL for the same env (found by hypothesis: size 6, n_clutter 50)
+        assert n_clutter + 1 >= interior
+        return
+    assert ex[0] == 0
     g = x.get_encodings()
     assert ((g[..., 0] == 8).sum(axis=(1, 2)) == 1).all() and ((g[..., 0] == 10).sum(axis=(1, 2)) == 1).all()
     border = np.ones((size, size), bool); border[1:-1, 1:-1] = False
@@ -51,7 +60,7 @@ def test_teacher_then_student_invariants(seed, size, view, n_clutter, goal_last)
     mg_diff.compare_state(x, y, "end")
 
 
-@settings(max_examples=30, deadline=None)
+@settings(max_examples=30, deadline=None, derandomize=True)
 @given(seed=st.integers(0, 2 ** 31 - 1), T=st.integers(1, 70), B=st.integers(1, 9), gamma=st.floats(0.9, 1.0), lam=st.floats(0.0, 1.0))
 def test_gae_reduces_to_known_cases(seed, T, B, gamma, lam):
     rng = np.random.default_rng(seed)
@@ -72,7 +81,7 @@ def test_gae_reduces_to_known_cases(seed, T, B, gamma, lam):
     np.testing.assert_allclose(d[:-1], ref, rtol=1e-4, atol=1e-4)
 
 
-@settings(max_examples=30, deadline=None)
+@settings(max_examples=30, deadline=None, derandomize=True)
 @given(seed=st.integers(0, 2 ** 31 - 1), T=st.integers(1, 60), B=st.integers(1, 8), p_done=st.floats(0.0, 0.6))
 def test_episode_records_partition_the_rollout(seed, T, B, p_done):
     """Records of one env tile [first segment start, T) without gaps or overlaps, in time order; every full record
