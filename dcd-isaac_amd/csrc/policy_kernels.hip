@@ -83,6 +83,52 @@ __global__ void __launch_bounds__(PB) policy_features_kernel(DcdStudentNet n, co
   }
 }
 
+// ---- features of a grid-sized observation (the teacher: 15 x 15 image, F = 128 filters, time-step embedding, z) -----
+// One workgroup per env.  Thread <-> conv output position (P = (S-2)^2 <= 256): its 27-value window sits in registers,
+// the loop runs over the F filters with the filter's 27 weights as LDS broadcasts; for a fixed filter the P threads
+// write P consecutive floats of the row.  Row layout as the module's cat (multigrid_models.py:119-131):
+// [relu(conv) flattened [F][P] | scalar_embed(one_hot(scalar)) | random_z | h * mask], pitch KP.
+constexpr int GMAXS = 17, GMAXF = 128;
+__global__ void __launch_bounds__(PB) grid_features_kernel(DcdStudentNet n, const float* __restrict__ image, const float* __restrict__ scalar,
+                                                           const float* __restrict__ z, int Z, const float* __restrict__ hc,
+                                                           const float* __restrict__ masks, float* __restrict__ x, int KP, int B) {
+  __shared__ float s_img[3 * GMAXS * GMAXS];
+  __shared__ float s_w[GMAXF * 27 + GMAXF];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int S = n.V, O = S - 2, P = O * O, F = n.F, E = n.E, H = n.H, CF = F * P, IMG = 3 * S * S;
+  float* row = x + (size_t)b * KP;
+  // independent global loads first: h, mask, embedding gather, z
+  float hv = 0.f, ev = 0.f, zv = 0.f;
+  const float m = masks[b];
+  if (tid < H) hv = hc[(size_t)b * 2 * H + tid] * m;
+  if (tid < E) { int d = (int)scalar[b]; d = d < 0 ? 0 : (d >= n.D ? n.D - 1 : d); ev = n.embed_w[tid * n.D + d] + n.embed_b[tid]; }
+  if (tid < Z) zv = z[(size_t)b * Z + tid];
+  for (int q = tid; q < IMG; q += PB) s_img[q] = image[(size_t)b * IMG + q];
+  for (int q = tid; q < F * 27; q += PB) s_w[q] = n.conv_w[q];
+  for (int q = tid; q < F; q += PB) s_w[GMAXF * 27 + q] = n.conv_b[q];
+  if (tid < E) row[CF + tid] = ev;
+  if (tid < Z) row[CF + E + tid] = zv;
+  if (tid < H) row[CF + E + Z + tid] = hv;
+  __syncthreads();
+  if (tid < P) {
+    const int oy = tid / O, ox = tid - oy * O;
+    float win[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) win[c * 9 + ky * 3 + kx] = s_img[c * S * S + (oy + ky) * S + ox + kx];
+    for (int f = 0; f < F; ++f) {
+      const float* w = s_w + f * 27;
+      float acc = s_w[GMAXF * 27 + f];
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc = fmaf(w[k], win[k], acc);
+      row[f * P + tid] = fmaxf(acc, 0.f);
+    }
+  }
+}
+
 // ---- LSTM pointwise + heads + sampling ----------------------------------------------------------
 // rollout-time activations on the hardware exp/rcp (v_exp_f32 / v_rcp_f32, ~1 ulp each): |error| < 3e-7 on outputs in
 // [-1,1], inside the 3e-6 tolerance against the PyTorch module (tests/test_gpu_policy.py).  The TRAINING kernels
@@ -296,6 +342,19 @@ int dcd_policy_features(const DcdStudentNet* net, const float* image, const floa
   else
     hipLaunchKernelGGL((policy_features_kernel<0, 0, 0, 0>), grid, block, 0, (hipStream_t)stream, *net, image, direction, hc, masks, x, x_pitch, B);
   if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_features: launch failed");
+  return 0;
+}
+
+int dcd_policy_grid_features(const DcdStudentNet* net, const float* image, const float* scalar, const float* z, int32_t z_dim,
+                             const float* hc, const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream) {
+  if (!net) return dcd::fail("dcd_policy_grid_features: net is NULL");
+  const int P = (net->V - 2) * (net->V - 2);
+  if (net->V < 3 || net->V > GMAXS || P > PB || net->F < 1 || net->F > GMAXF) return dcd::fail("dcd_policy_grid_features: unsupported conv geometry S=%d F=%d", net->V, net->F);
+  if (net->H < 1 || net->H > PB || net->E < 0 || net->E > PB || net->D < 1 || z_dim < 0 || z_dim > PB) return dcd::fail("dcd_policy_grid_features: unsupported widths");
+  if (!image || !scalar || !hc || !masks || !x || (z_dim && !z) || B <= 0) return dcd::fail("dcd_policy_grid_features: NULL pointer or B <= 0");
+  if (x_pitch < net->F * P + net->E + z_dim + net->H) return dcd::fail("dcd_policy_grid_features: x_pitch %d too small", x_pitch);
+  hipLaunchKernelGGL(grid_features_kernel, dim3(B), dim3(PB), 0, (hipStream_t)stream, *net, image, scalar, z, z_dim, hc, masks, x, x_pitch, B);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_grid_features: launch failed");
   return 0;
 }
 

@@ -144,3 +144,94 @@ class StudentActor:
         self.act_into(st.obs["image"][step], st.obs["direction"][step], st.recurrent_hidden_states[step], st.masks[step],
                       st.recurrent_hidden_states[step + 1], st.value_preds[step], st.actions[step], st.action_log_probs[step],
                       st.action_log_dist[step], deterministic=deterministic)
+
+
+class GridActor:
+    """Rollout-time policy step of a recurrent, grid-observing MultigridNetwork (the PAIRED teacher: 15 x 15 image,
+    128 filters, time-step embedding, random_z, LSTM-256): `dcd_policy_grid_features` writes the GEMM operand row
+    [relu(conv) | embed | z | h*mask] directly — the module path builds it through an im2col copy chain and a 355 MB
+    `cat` per step (0.9 of its 2.4 ms) — then ONE GEMM against the stacked [W_ih | W_hh]; the cell and the heads stay
+    PyTorch ops on [B, 256] tensors (169-way categorical: `torch.multinomial`, as in the reference)."""
+
+    def __init__(self, net, num_envs):
+        self.net, self.B = net, int(num_envs)
+        conv, lstm = net.image_conv[0], net.rnn.rnn
+        self.H, self._lstm = lstm.hidden_size, lstm
+        dev = conv.weight.device
+        F = conv.out_channels
+        P = net.image_embedding_size // F
+        S = int(round(P ** 0.5)) + 2
+        E, D = net.scalar_embed.out_features, net.scalar_embed.in_features
+        self.Z = net.preprocessed_input_size - net.image_embedding_size - E
+        self._dims = dict(V=S, F=F, E=E, D=D, H=self.H, A1=0, C1=0, NA=0)
+        self._params = [conv.weight, conv.bias, net.scalar_embed.weight, net.scalar_embed.bias]
+        self.K = F * P + E + self.Z + self.H
+        self.KP = (self.K + 31) // 32 * 32
+        self.x = torch.zeros((self.B, self.KP), device=dev)
+        self.gates = torch.empty((self.B, 4 * self.H), device=dev)
+        self.w_t = torch.zeros((self.KP, 4 * self.H), device=dev)
+        self.bias = torch.empty((4 * self.H,), device=dev)
+        self._struct, self._w_version = None, None
+        self.refresh()
+
+    @staticmethod
+    def supported(net):
+        try:
+            from models.multigrid_models import MultigridNetwork
+        except ImportError:
+            return False
+        if not isinstance(net, MultigridNetwork) or net.random or net.rnn is None or not net.rnn.is_lstm:
+            return False
+        conv = net.image_conv[0]
+        if not conv.weight.is_cuda or conv.kernel_size != (3, 3) or conv.in_channels != 3 or conv.out_channels > 128:
+            return False
+        if net.scalar_embed is None or net.xy_dim or net.rnn.rnn.num_layers != 1 or net.rnn.rnn.hidden_size > 256:
+            return False
+        P = net.image_embedding_size // conv.out_channels
+        S = int(round(P ** 0.5)) + 2
+        return (S - 2) ** 2 == P and 9 <= S <= 17 and net.scalar_embed.out_features <= 256
+
+    @classmethod
+    def try_create(cls, net, num_envs):
+        if not enabled() or not cls.supported(net):
+            return None
+        return cls(net, num_envs)
+
+    def refresh(self):
+        l = self._lstm
+        ver = tuple(p._version for p in (l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0)) + \
+            tuple(p.data_ptr() for p in self._params)
+        if ver == self._w_version:
+            return
+        with torch.no_grad():
+            self.w_t[:self.K - self.H].copy_(l.weight_ih_l0.t())
+            self.w_t[self.K - self.H:self.K].copy_(l.weight_hh_l0.t())
+            torch.add(l.bias_ih_l0, l.bias_hh_l0, out=self.bias)
+        s = StudentNet()
+        for name, p in zip(("conv_w", "conv_b", "embed_w", "embed_b"), self._params):
+            setattr(s, name, ptr(p.detach(), torch.float32, name=name).value)
+        for k, v in self._dims.items():
+            setattr(s, k, v)
+        self._struct, self._w_version = s, ver
+
+    def act(self, obs, hc_in, masks, deterministic=False):
+        """`net.act(obs, (h, c), masks)` (multigrid_models.py:141-167): value [B,1], action [B,1], normalised logits
+        [B,A], (h', c').  obs: dict with image / time_step (or direction) / random_z; hc_in: [B, 2H] = h | c."""
+        B, H, s = self.B, self.H, self._struct
+        scalar = obs.get("direction")
+        if scalar is None:
+            scalar = obs.get("time_step")
+        z = obs.get("random_z") if self.Z else None
+        check(lib().dcd_policy_grid_features(
+            C.byref(s), ptr(obs["image"], torch.float32, B * 3 * self._dims["V"] ** 2, "image"), ptr(scalar, torch.float32, B, "scalar"),
+            ptr(z, torch.float32, B * self.Z, "random_z") if z is not None else None, C.c_int32(self.Z),
+            ptr(hc_in, torch.float32, B * 2 * H, "hc_in"), ptr(masks, torch.float32, B, "masks"), ptr(self.x), C.c_int32(self.KP),
+            C.c_int32(B), stream_ptr()))
+        torch.addmm(self.bias, self.x, self.w_t, out=self.gates)
+        i, f, g, o = self.gates.split(H, dim=1)
+        c = torch.sigmoid(f) * (hc_in[:, H:] * masks) + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        dist = self.net.actor(h)
+        value = self.net.critic(h)
+        action = dist.mode() if deterministic else dist.sample()
+        return value, action, dist.logits, (h, c)

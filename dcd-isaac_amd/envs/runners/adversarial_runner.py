@@ -324,16 +324,33 @@ class AdversarialRunner:
         agent.storage.step = 0
         self.ued_venv.raise_errors()
 
+    def _grid_actor(self, agent):
+        """dcd_hip.policy.GridActor for a recurrent teacher (features kernel + one stacked GEMM), or None."""
+        ga = getattr(agent, "_grid_actor", False)
+        if ga is False:
+            from dcd_hip.policy import GridActor
+            ga = GridActor.try_create(agent.actor_critic, self.args.num_processes) if self.device.type == "cuda" else None
+            agent._grid_actor = ga
+        if ga is not None and agent.actor_critic.random:
+            return None
+        return ga
+
     def _teacher_rollout_body(self, agent, t0, t1):
         """Constructive teacher episode, steps [t0, t1) (:481, :497-592 with is_env=True)."""
         st, venv, B = agent.storage, self.ued_venv, self.args.num_processes
         if t0 == 0:
             venv.reset_device(st.adversary_obs_out(0))
         st.step = t0
+        grid_actor = self._grid_actor(agent) if self.is_discrete_adversary_env_actions else None
+        if grid_actor is not None:
+            grid_actor.refresh()
         for step in range(t0, t1):
             with torch.no_grad():
-                value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step),
-                                                         st.masks[step])
+                if grid_actor is not None:
+                    value, action, log_dist, hxs = grid_actor.act(st.get_obs(step), st.recurrent_hidden_states[step], st.masks[step])
+                else:
+                    value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step),
+                                                             st.masks[step])
                 log_prob = log_dist.gather(-1, action) if self.is_discrete_adversary_env_actions else log_dist
             st.insert_policy(hxs, action, log_prob, log_dist, value)
             out = st.adversary_obs_out(step + 1)

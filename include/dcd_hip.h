@@ -323,6 +323,13 @@ int dcd_policy_input_width(const DcdStudentNet* net);
  * masks: float[B].  The caller then forms gates = x @ [W_ih | W_hh]^T + (b_ih + b_hh) (one GEMM). */
 int dcd_policy_features(const DcdStudentNet* net, const float* image, const float* direction, const float* hc,
                         const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream);
+/* The same row for a grid-sized observation (the teacher, multigrid_models.py:109-139, util/make_agent.py:22-36):
+ * x[b] = [relu(conv(image[b])) flattened [F][(S-2)^2] | scalar_embed(one_hot(scalar[b])) | z[b] | h[b]*masks[b]].
+ * Only conv_w, conv_b, embed_w, embed_b and V (= S <= 17), F (<= 128), E, D, H of `net` are read.  image:
+ * float[B,3,S,S], scalar: float[B] (time_step), z: float[B,z_dim] (random_z; NULL with z_dim 0), x: float[B,x_pitch]. */
+int dcd_policy_grid_features(const DcdStudentNet* net, const float* image, const float* scalar, const float* z,
+                             int32_t z_dim, const float* hc, const float* masks, float* x, int32_t x_pitch, int32_t B,
+                             void* stream);
 /* Head weights re-laid out for the kernel below (stacked + transposed first layers, padded second layers):
  * packed: float[dcd_policy_packed_heads_floats()]; call again whenever the optimiser has stepped. */
 int dcd_policy_packed_heads_floats(void);

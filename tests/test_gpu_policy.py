@@ -266,3 +266,30 @@ def test_split_k_linear_matches_plain_linear():
         a2, b2 = torch.randn(R, m, device=DEV), torch.randn(R, k, device=DEV)
         ref = a2.t() @ b2
         assert (matmul_tn(a2, b2) - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_grid_actor_matches_teacher_module():
+    """GridActor (dcd_policy_grid_features + one stacked GEMM + the module's own heads) vs MultigridNetwork.act on a
+    teacher rollout's observations: value, normalised logits and (h', c') within fp32 round-off of the 21 948-term
+    dot products (1e-5 relative to each tensor's scale); deterministic actions equal where the top-2 gap is clear."""
+    from dcd_hip.policy import GridActor
+    from tests.test_gpu_runner import build, make_args
+    args = make_args(ued_algo="paired", num_processes=40)
+    runner, venv = build(args)
+    teacher = runner.agents["adversary_env"]
+    net, st = teacher.algo.actor_critic, teacher.storage
+    assert GridActor.supported(net)
+    runner._teacher_rollout(teacher, runner.adversary_env_rollout_steps)       # itself on the GridActor path
+    ga = GridActor(net, 40)
+    for step in (0, 5, 26):
+        obs, hc, masks = st.get_obs(step), st.recurrent_hidden_states[step], st.masks[step]
+        with torch.no_grad():
+            v0, a0, l0, (h0, c0) = net.act(obs, st.get_recurrent_hidden_state(step), masks, deterministic=True)
+            v1, a1, l1, (h1, c1) = ga.act(obs, hc, masks, deterministic=True)
+        for n, a, b in (("value", v0, v1), ("logits", l0, l1), ("h", h0, h1), ("c", c0, c1)):
+            assert (a - b).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1.0), (step, n, (a - b).abs().max().item())
+        top2 = l0.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert torch.equal(a0[clear], a1[clear])
+    assert st.actions.min() >= 0 and st.actions.max() < 169 and torch.isfinite(st.value_preds).all()
+    venv.close()
