@@ -272,13 +272,16 @@ def end_to_end_leg(B, T, device, updates):
     agents = [make_agent(n, venv, a, device) for n in ("agent", "adversary_agent", "adversary_env")]
     runner = AdversarialRunner(args=a, venv=venv, agent=agents[0], ued_venv=ued, adversary_agent=agents[1],
                                adversary_env=agents[2], train=True, device=device)
-    runner.run()                                                  # warm-up (allocator, GEMM heuristics)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(updates):
+    for _ in range(2):                                            # warm-up: allocator, GEMM heuristics, then HIP-graph capture
         runner.run()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / updates
+    per_update = []
+    for _ in range(updates):
+        t0 = time.perf_counter()
+        runner.run()
+        torch.cuda.synchronize()
+        per_update.append(time.perf_counter() - t0)
+    dt = sum(per_update) / updates
     t0 = time.perf_counter()
     runner._student_rollout(agents[0], T, False, None, {})
     torch.cuda.synchronize()
@@ -287,6 +290,7 @@ def end_to_end_leg(B, T, device, updates):
     return {"S_roll_env_steps_per_s": B * T / roll, "student_rollout_ms": roll * 1e3,
             "S_train_sps_reference_formula": B * T / dt,                    # train.py:184 counts one student rollout per update
             "S_train_true_env_steps_per_s": (2 * B * T + B * 27) / dt, "seconds_per_update": dt, "updates_timed": updates,
+            "seconds_each_update": [round(x, 4) for x in per_update],
             "what": "AdversarialRunner.run(), PAIRED, LSTM-256 students (433 953 params) + recurrent teacher (22 502 732 params), "
                     "PPO 5 epochs x 1 minibatch, fp32; student rollouts: fused HIP policy step + env step replayed as HIP graphs; "
                     "PPO: PyTorch-ROCm with the masked LSTM as one autograd node over HIP pointwise kernels"}
