@@ -73,3 +73,73 @@ extern "C" int dcd_action_complexity(const int64_t* actions, const float* masks,
   if (n_episodes) *n_episodes = n;
   return 0;
 }
+
+// ---- LevelSampler: a batch of sequential replay draws (level_replay/level_sampler.py:664-750) ------------------
+// The draws of one batch are sequential by definition (each one zeroes the chosen seed's staleness and ages the
+// others), and each is O(N) numpy calls on the buffer: 4096 draws up front plus one per finished episode bound a
+// replay update at 4096 envs per GPU (0.4 s on the host next to 0.25 s of GPU work).  This loop performs the SAME
+// IEEE operations in the SAME order as the numpy statement in LevelSampler.sample_replay_levels — elementwise
+// products / quotients, numpy's pairwise summation for np.sum, a running sum for cumsum, a right-sided binary search —
+// for the common configuration (staleness transform 'power' with temperature 1).  The Python side keeps the numpy
+// loop, checks this one against it on random inputs before first use, and takes over from the draw at which this
+// loop meets a case it does not handle.
+namespace {
+
+// numpy/core/src/umath/loops_utils.h.src: pairwise summation of a contiguous double array
+double np_pairwise_sum(const double* a, long n) {
+  if (n < 8) {
+    double res = 0.;
+    for (long i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    long i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  long n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+}  // namespace
+
+extern "C" double dcd_np_sum(const double* a, int64_t n) { return np_pairwise_sum(a, (long)n); }
+
+// returns the number of draws performed (== n unless an unhandled case stopped the loop early).
+// target_clones: an AVX2 build of the elementwise passes where the host has it (no FMA contraction either way).
+extern "C" __attribute__((target_clones("avx2", "default")))
+int64_t dcd_sampler_draws(int64_t N, int64_t n, const double* w_scores, double c, double* staleness, const double* unseen_keep,
+                          const double* uniforms, int32_t update_staleness, int64_t* out_idx) {
+  std::vector<double> sw_((size_t)N), w_((size_t)N), cdf_((size_t)N);
+  double* __restrict__ sw = sw_.data(); double* __restrict__ w = w_.data(); double* __restrict__ cdf = cdf_.data();
+  for (int64_t k = 0; k < n; ++k) {
+    double smin = staleness[0];
+    for (int64_t i = 0; i < N; ++i) { sw[i] = staleness[i] * unseen_keep[i]; smin = staleness[i] < smin ? staleness[i] : smin; }
+    if (smin < 0) return k;
+    const double z = np_pairwise_sum(sw, (long)N);
+    if (!(z > 0)) return k;
+    for (int64_t i = 0; i < N; ++i) { const double q = sw[i] / z; const double t = c * q; w[i] = w_scores[i] + t; }
+    const double total = np_pairwise_sum(w, (long)N);
+    if (!(total > 1e-8 || total < -1e-8)) return k;                  // np.isclose(total, 0): the uniform fallback stays in Python
+    if (total != 1.0) for (int64_t i = 0; i < N; ++i) w[i] = w[i] / total;
+    double run = 0., mn = w[0];
+    for (int64_t i = 0; i < N; ++i) { run += w[i]; cdf[i] = run; mn = w[i] < mn ? w[i] : mn; }
+    const double last = cdf[N - 1];
+    if (!(last - 1.0 <= 1e-8 && 1.0 - last <= 1e-8) || mn < 0) return k;
+    const double u = uniforms[k];
+    int64_t lo = 0, hi = N;                                          // searchsorted(cdf / last, u, side='right')
+    while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (cdf[mid] / last <= u) lo = mid + 1; else hi = mid; }
+    out_idx[k] = lo;
+    if (update_staleness) {
+      for (int64_t i = 0; i < N; ++i) staleness[i] = staleness[i] + 1;
+      if (lo < N) staleness[lo] = 0;
+    }
+  }
+  return n;
+}

@@ -29,6 +29,51 @@ _VALUE_STRATEGIES = ("gae", "value_l1", "signed_value_loss", "positive_value_los
                      "grounded_positive_value_loss", "one_step_td_error", "alt_advantage_abs", "tscl_window")
 
 
+_NATIVE_DRAWS = None
+
+
+def _native_draws_available():
+    """True when libdcd_hip's dcd_sampler_draws reproduces the numpy draw loop bit for bit on this machine (checked once
+    on a random buffer: indices and final staleness must be identical); DCD_NATIVE_SAMPLER=0 disables it."""
+    global _NATIVE_DRAWS
+    if _NATIVE_DRAWS is None:
+        import os
+        _NATIVE_DRAWS = False
+        if os.environ.get("DCD_NATIVE_SAMPLER", "1") != "0":
+            try:
+                import ctypes as C
+                from dcd_hip import lib
+                L = lib()
+                L.dcd_sampler_draws.restype = C.c_int64
+                rng = np.random.RandomState(12345)
+                N, n, c = 257, 64, 0.3
+                wsc = (1 - c) * (lambda v: v / v.sum())(rng.rand(N))
+                keep = (rng.rand(N) > 0.2).astype(np.float64)
+                st0 = rng.randint(0, 30, N).astype(np.float64)
+                u = rng.random_sample(n)
+                st, idx = st0.copy(), np.empty(n, dtype=np.int64)
+                p_ = lambda a: a.ctypes.data_as(C.c_void_p)
+                k = L.dcd_sampler_draws(C.c_int64(N), C.c_int64(n), p_(wsc), C.c_double(c), p_(st), p_(keep), p_(u), C.c_int32(1), p_(idx))
+                ref_st, ref_idx = st0.copy(), []
+                for j in range(n):
+                    sw = ref_st * keep
+                    sw /= np.sum(sw)
+                    w = wsc + c * sw
+                    total = np.sum(w)
+                    if total != 1.0:
+                        w = w / total
+                    cdf = w.cumsum()
+                    cdf /= cdf[-1]
+                    i = int(cdf.searchsorted(u[j:j + 1], side="right")[0])
+                    ref_idx.append(i)
+                    ref_st = ref_st + 1
+                    ref_st[i] = 0
+                _NATIVE_DRAWS = bool(k == n and idx.tolist() == ref_idx and np.array_equal(st, ref_st))
+            except Exception:
+                _NATIVE_DRAWS = False
+    return _NATIVE_DRAWS
+
+
 class LevelSampler:
     def __init__(self, seeds, obs_space, action_space, num_actors=1, strategy="random", max_score_coef=0.0,
                  replay_schedule="fixed", score_transform="power", temperature=1.0, eps=0.05, rho=1.0,
@@ -418,8 +463,23 @@ class LevelSampler:
         w_scores = (1 - c) * ws if c > 0 else ws                     # constant across the batch of draws
         # 'power' with temperature 1 and eps 0 (staleness_coef > 0): (clip(s, 0) + 0) ** 1.0 is s itself, bit for bit
         plain_staleness = self.staleness_transform == "power" and self.staleness_temperature == 1.0
-        out = []
-        for _ in range(n):
+        uniforms = np.random.random_sample(n)                        # the n doubles n calls of choice(..., 1, p=w) would draw
+        out, k = [], 0
+        if c > 0 and plain_staleness and _native_draws_available():
+            # the same loop in C (dcd_sampler_draws, csrc/host_utils.cpp): same IEEE operations in the same order
+            import ctypes as C
+            from dcd_hip import lib
+            st = np.ascontiguousarray(self.seed_staleness, dtype=np.float64).copy()
+            idx = np.empty(n, dtype=np.int64)
+            p_ = lambda a: a.ctypes.data_as(C.c_void_p)
+            wsc, keep = np.ascontiguousarray(w_scores, dtype=np.float64), np.ascontiguousarray(unseen_keep, dtype=np.float64)
+            k = int(lib().dcd_sampler_draws(C.c_int64(N), C.c_int64(n), p_(wsc), C.c_double(c), p_(st), p_(keep), p_(uniforms),
+                                            C.c_int32(int(update_staleness)), p_(idx)))
+            self.seed_staleness = st
+            if update_staleness and k:
+                self._state_version = getattr(self, "_state_version", 0) + 1
+            out = [int(self.seeds[i]) for i in idx[:k]]
+        for j in range(k, n):                                        # numpy statement (and continuation of the C loop)
             if c > 0:
                 if plain_staleness and self.seed_staleness.min() >= 0:
                     sw = self.seed_staleness * unseen_keep
@@ -446,7 +506,7 @@ class LevelSampler:
                 seed_idx = np.random.choice(range(N), 1, p=w)[0]
             else:
                 cdf /= cdf[-1]
-                seed_idx = int(cdf.searchsorted(np.random.random_sample(1), side="right")[0])
+                seed_idx = int(cdf.searchsorted(uniforms[j:j + 1], side="right")[0])
             if update_staleness:
                 self._update_staleness(seed_idx)
             out.append(int(self.seeds[seed_idx]))

@@ -375,6 +375,16 @@ int dcd_lstm_seq_bwd_step(const float* act, const float* c_t, const float* c_pre
 int dcd_action_complexity(const int64_t* actions, const float* masks, int32_t T, int32_t B, double* total,
                           int64_t* n_episodes, float* per_env);
 
+/* LevelSampler.sample_replay_levels (level_replay/level_sampler.py:664-750 as n sequential draws): the same IEEE
+ * operations in the same order as the numpy statement, for staleness transform 'power' with temperature 1.  HOST
+ * pointers: w_scores double[N] = (1 - c) * score weights, staleness double[N] (updated in place), unseen_keep
+ * double[N] = 1 - unseen_seed_weights, uniforms double[n] (np.random.random_sample(n)), out_idx int64[n].  Returns the
+ * number of draws performed; < n when a case the loop does not cover occurred at that draw (the caller continues in
+ * numpy from there).  dcd_np_sum: numpy's pairwise summation (np.sum of a contiguous float64 array). */
+int64_t dcd_sampler_draws(int64_t N, int64_t n, const double* w_scores, double c, double* staleness,
+                          const double* unseen_keep, const double* uniforms, int32_t update_staleness, int64_t* out_idx);
+double dcd_np_sum(const double* a, int64_t n);
+
 /* ---- synthetic workload helpers (bench / tests only) ------------- */
 /* actions[t,i] = mulhi(philox(key=(seed, env_index_base+i), ctr=(t0+t,0,0,0))[0], num_actions);
  * actions: int64[T,B] */

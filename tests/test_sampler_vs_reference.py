@@ -147,3 +147,45 @@ def test_batched_replay_sampling_equals_sequential_calls(score_transform, stalen
     assert np.array_equal(state_a, state_b)
     assert np.array_equal(a.seed_staleness, b.seed_staleness)
     assert all(a.unseen_seed_weights[a.seed2index[sd]] == 0 for sd in bat)      # only seen levels are replayed
+
+
+def test_native_draw_loop_is_numpy_bit_for_bit(monkeypatch):
+    """dcd_sampler_draws / dcd_np_sum (csrc/host_utils.cpp, host memory): numpy's pairwise np.sum reproduced exactly,
+    and the C draw loop == the numpy draw loop == sequential sample_replay_level() calls (seeds, staleness, RNG state),
+    including a buffer with unseen slots; with the native loop switched off the numpy loop gives the same again."""
+    import ctypes as C
+    import level_replay.level_sampler as ls
+    from dcd_hip import lib
+    from level_replay import LevelSampler
+    L = lib()
+    L.dcd_np_sum.restype = C.c_double
+    rng = np.random.default_rng(0)
+    for n in list(range(1, 140)) + [255, 256, 257, 1000, 4000, 4001, 9999]:
+        a = rng.random(n) * rng.choice([1.0, 1e-6, 1e6])
+        assert L.dcd_np_sum(a.ctypes.data_as(C.c_void_p), C.c_int64(n)) == float(np.sum(a)), n
+    assert ls._native_draws_available()
+
+    class Space:
+        n = 7
+
+    def make():
+        s = LevelSampler([], None, Space(), num_actors=4, strategy="positive_value_loss", score_transform="rank", temperature=0.3,
+                         staleness_coef=0.3, sample_full_distribution=True, seed_buffer_size=500, rho=0.5, replay_prob=0.5)
+        r = np.random.default_rng(9)
+        s.seeds[:] = np.arange(5, 505)
+        s.seed2index = {int(sd): i for i, sd in enumerate(s.seeds)}
+        s.seed_scores[:] = r.random(500) * (r.random(500) > 0.2)
+        s.unseen_seed_weights[:] = (r.random(500) > 0.85).astype(np.float64)
+        s.seed_staleness[:] = r.integers(0, 25, 500)
+        s.working_seed_buffer_size = 500
+        return s
+
+    results = []
+    for mode in ("sequential", "native", "numpy"):
+        s = make()
+        monkeypatch.setattr(ls, "_NATIVE_DRAWS", mode == "native")
+        np.random.seed(77)
+        seeds = [s.sample_replay_level() for _ in range(300)] if mode == "sequential" else s.sample_replay_levels(300)
+        results.append((seeds, s.seed_staleness.copy(), np.random.get_state()[1].copy()))
+    for seeds, stale, state in results[1:]:
+        assert seeds == results[0][0] and np.array_equal(stale, results[0][1]) and np.array_equal(state, results[0][2])
