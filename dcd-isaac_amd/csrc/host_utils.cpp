@@ -9,6 +9,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <vector>
+#include <exception>
 #include "../../include/dcd_hip.h"
 #include "dcd_internal.h"
 
@@ -47,6 +48,7 @@ int lz76(const char* s, int n, std::vector<Slot>& table) {
 extern "C" int dcd_action_complexity(const int64_t* actions, const float* masks, int32_t T, int32_t B, double* total,
                                      int64_t* n_episodes, float* per_env) {
   if (!actions || !masks || T <= 0 || B <= 0) return dcd::fail("dcd_action_complexity: NULL pointer or empty rollout");
+  try {
   std::vector<char> str((size_t)T * 21 + 1);
   std::vector<int> cuts(T + 3);
   std::vector<Slot> table(4096);
@@ -72,6 +74,7 @@ extern "C" int dcd_action_complexity(const int64_t* actions, const float* masks,
   if (total) *total = tot;
   if (n_episodes) *n_episodes = n;
   return 0;
+  } catch (const std::exception& e) { return dcd::fail("dcd_action_complexity: %s", e.what()); }   // no C++ exception crosses the C ABI
 }
 
 // ---- LevelSampler: a batch of sequential replay draws (level_replay/level_sampler.py:664-750) ------------------
@@ -116,7 +119,9 @@ extern "C" double dcd_np_sum(const double* a, int64_t n) { return np_pairwise_su
 extern "C" __attribute__((target_clones("avx2", "default")))
 int64_t dcd_sampler_draws(int64_t N, int64_t n, const double* w_scores, double c, double* staleness, const double* unseen_keep,
                           const double* uniforms, int32_t update_staleness, int64_t* out_idx) {
-  std::vector<double> sw_((size_t)N), w_((size_t)N), cdf_((size_t)N);
+  if (N <= 0 || n <= 0 || !w_scores || !staleness || !unseen_keep || !uniforms || !out_idx) return 0;
+  std::vector<double> sw_, w_, cdf_;
+  try { sw_.resize((size_t)N); w_.resize((size_t)N); cdf_.resize((size_t)N); } catch (const std::exception&) { return 0; }   // caller continues in numpy
   double* __restrict__ sw = sw_.data(); double* __restrict__ w = w_.data(); double* __restrict__ cdf = cdf_.data();
   for (int64_t k = 0; k < n; ++k) {
     double smin = staleness[0];
