@@ -336,8 +336,23 @@ class HipAdversarialVecEnv:
             vals = [vals[i] for i in index]
         return vals
 
-    def get_images(self):
-        raise NotImplementedError("level rendering (multigrid.py:212-261) is UI, outside the GPU hot path")
+    def get_images(self, index=None):
+        """One RGB image per env of its current grid with the agent drawn in (parallel_wrappers.py:187-193 ->
+        env.render('level'), multigrid.py:212-261): host-side, from the encodings and the agent state
+        (envs/multigrid/rendering.py).  `index` limits the envs rendered (the reference renders all of them and
+        the caller slices; at 4096 envs that is seconds of host work for one screenshot)."""
+        from envs.multigrid.rendering import render_levels
+        enc = self.engine.get_encodings().cpu().numpy()
+        st = self.engine.get_state().cpu().numpy()
+        index = range(len(enc)) if index is None else index
+        out = []
+        for i in index:
+            e = enc[i].copy()
+            ax, ay, ad = int(st[i, 0]), int(st[i, 1]), int(st[i, 2])
+            if 0 <= ax < e.shape[0] and 0 <= ay < e.shape[1]:
+                e[ax, ay] = (10, 0, ad)
+            out.append(e)
+        return render_levels(out) if out else []
 
     def render_to_screen(self):
         raise NotImplementedError("on-screen rendering is outside the GPU hot path")

@@ -62,8 +62,30 @@ def safe_checkpoint(state_dict, path, index=None, archive_interval=None):
         shutil.copy(path, f"{filename}_{index}{ext}")
 
 
-def save_images(images, path=None, normalize=False, channels_first=False):
-    raise NotImplementedError("level screenshots (train.py:204-232) are UI, outside the GPU hot path")
+def save_images(images, path=None, normalize=False, channels_first=False, nrow=8, padding=2):
+    """Tile `images` (list of HWC uint8 arrays) into one grid image and write it as PNG (reference: util/__init__.py
+    save_images -> torchvision make_grid/save_image, 8 per row, 2-pixel black padding; torchvision is not a
+    dependency here, the grid is assembled in numpy and written with PIL)."""
+    import numpy as np
+    if path is None or len(images) == 0:
+        return
+    arr = [np.asarray(im) for im in images]
+    if channels_first:
+        arr = [a.transpose(1, 2, 0) for a in arr]
+    if normalize:
+        arr = [(255.0 * (a - a.min()) / max(float(a.max() - a.min()), 1e-5)) for a in arr]
+    arr = [np.clip(a, 0, 255).astype(np.uint8) for a in arr]
+    h, w = arr[0].shape[:2]
+    n = len(arr)
+    cols = min(nrow, n)
+    rows = (n + cols - 1) // cols
+    canvas = np.zeros((rows * (h + padding) + padding, cols * (w + padding) + padding, 3), dtype=np.uint8)
+    for i, a in enumerate(arr):
+        r, c = divmod(i, cols)
+        y0, x0 = padding + r * (h + padding), padding + c * (w + padding)
+        canvas[y0:y0 + h, x0:x0 + w] = a
+    from PIL import Image
+    Image.fromarray(canvas).save(path)
 
 
 def get_obs_at_index(obs, i):

@@ -34,12 +34,17 @@ def test_train_cli_logs_evaluates_checkpoints_and_resumes(tmp_path):
               "--ued_algo=paired", "--num_processes=32", "--num_steps=32", "--ppo_epoch=1", "--adv_ppo_epoch=1",
               "--recurrent_adversary_env=True", "--handle_timelimits=True", "--log_interval=1", "--checkpoint=True",
               "--checkpoint_interval=2", "--test_interval=2", "--test_num_episodes=4", "--test_num_processes=4",
-              "--test_env_names=MultiGrid-SixteenRooms-v0,MultiGrid-PerfectMazeSmall-v0", "--log_action_complexity=True"]
+              "--test_env_names=MultiGrid-SixteenRooms-v0,MultiGrid-PerfectMazeSmall-v0", "--log_action_complexity=True",
+              "--screenshot_interval=3", "--screenshot_batch_size=4"]
     out = _run(common + ["--num_env_steps=4096"])                   # 4 updates of 32 x 32 steps
     d = os.path.join(str(tmp_path), "cli")
     assert os.path.exists(os.path.join(d, "meta.json")) and os.path.exists(os.path.join(d, "model.tar"))
     meta = json.load(open(os.path.join(d, "meta.json")))
     assert meta["args"]["ued_algo"] == "paired" and meta["args"]["num_processes"] == 32
+    from PIL import Image                                            # level screenshots at updates 0 and 3 (train.py:204-232)
+    assert sorted(os.listdir(os.path.join(d, "screenshots"))) == ["update0.png", "update3.png"]
+    shot = Image.open(os.path.join(d, "screenshots", "update3.png"))
+    assert shot.size == (4 * (15 * 32 + 2) + 2, 15 * 32 + 4)
     rows = _rows(os.path.join(d, "logs.csv"))
     assert len(rows) == 4 and [int(float(r["steps"])) for r in rows] == [1024, 2048, 3072, 4096]
     for k in ("sps", "mean_agent_return", "agent_value_loss", "adversary_env_value_loss", "mean_env_return", "agent_action_complexity",

@@ -9,7 +9,8 @@ on the MI355X engine.  One process per GPU (launch with torch.distributed.run fo
 Logs go to <log_dir>/<xpid>/{logs.csv, fields.csv, meta.json} in the reference's layout (util/filewriter.py) and
 to stdout as JSON lines; checkpoints use the reference's `runner_state_dict` layout through util.safe_checkpoint;
 every --test_interval updates the student is evaluated zero-shot on --test_env_names (eval.Evaluator, the
-15x15 mazes).  Level screenshots (train.py:204-232 of the reference) are UI and not built.
+15x15 mazes); every --screenshot_interval updates the first --screenshot_batch_size levels are written to
+<log_dir>/<xpid>/screenshots/ (train.py:204-232; host-side renderer, envs/multigrid/rendering.py).
 """
 import json
 import os
@@ -24,7 +25,7 @@ import torch  # noqa: E402
 
 from arguments import parser  # noqa: E402
 from envs.runners import AdversarialRunner  # noqa: E402
-from util import create_parallel_env, make_agent, make_plr_args, safe_checkpoint, seed  # noqa: E402
+from util import create_parallel_env, make_agent, make_plr_args, safe_checkpoint, save_images, seed  # noqa: E402
 from util import distributed as D  # noqa: E402
 from util.filewriter import FileWriter  # noqa: E402
 
@@ -88,6 +89,15 @@ def main():
         if rank == 0 and args.checkpoint and j > 0 and j % args.checkpoint_interval == 0:
             os.makedirs(os.path.dirname(ckpt), exist_ok=True)
             safe_checkpoint({"runner_state_dict": runner.state_dict()}, ckpt, index=j, archive_interval=args.archive_interval)
+        if rank == 0 and args.screenshot_interval > 0 and j % args.screenshot_interval == 0:     # train.py:169-171,204-232
+            shot_dir = os.path.join(os.path.dirname(ckpt), "screenshots")
+            os.makedirs(shot_dir, exist_ok=True)
+            info = runner.sampled_level_info
+            name = (f"update{j}-replay{info['level_replay']}-n_edits{info['num_edits'][0]}.png"
+                    if args.use_editor and info else f"update{j}.png")
+            venv.reset_agent()
+            save_images(venv.get_images(range(min(args.screenshot_batch_size, args.num_processes))),
+                        os.path.join(shot_dir, name), normalize=True, channels_first=False)
     if writer is not None:
         writer.close()
     if evaluator is not None:
