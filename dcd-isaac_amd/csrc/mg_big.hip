@@ -34,7 +34,7 @@ namespace {
 
 struct Big {
   DcdMgConfig cfg; Params p; int device;
-  uint8_t* rec; uint32_t* seed; Metrics* met; uint32_t* errs;
+  uint8_t* rec = nullptr; uint32_t* seed = nullptr; Metrics* met = nullptr; uint32_t* errs = nullptr;
 };
 
 constexpr int TB = 64;
@@ -167,6 +167,8 @@ inline int blocks(int n) { return (n + TB - 1) / TB; }
 
 extern "C" {
 
+int SFX(dcd_big_destroy)(void* hv);
+
 int SFX(dcd_big_create)(const DcdMgConfig* cfg, int device, void** out) {
   if (cfg->size > MAX_SIZE) return dcd::fail("size %d exceeds this build's pitch", cfg->size);
   HIP_OK(hipSetDevice(device));
@@ -182,15 +184,21 @@ int SFX(dcd_big_create)(const DcdMgConfig* cfg, int device, void** out) {
   p.fixed_environment = cfg->fixed_environment; p.goal_noise = cfg->goal_noise; p.engine_seed = cfg->engine_seed;
   p.see_through_walls = cfg->see_through_walls != 0;
   const size_t B = (size_t)p.B;
-  if (hipMalloc(&h->rec, B * REC_BYTES) != hipSuccess || hipMalloc(&h->seed, B * 4) != hipSuccess ||
-      hipMalloc(&h->met, B * sizeof(Metrics)) != hipSuccess || hipMalloc(&h->errs, 8) != hipSuccess) {
-    delete h; return dcd::fail("hipMalloc failed for %zu envs of %d bytes", B, REC_BYTES);
-  }
   const uint32_t init[2] = {0u, 0x7fffffffu};
-  HIP_OK(hipMemcpy(h->errs, init, 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(big_init_kernel, dim3(blocks(p.B)), dim3(TB), 0, 0, p, h->rec, h->seed, h->met, (long long)cfg->env_index_base);
-  HIP_OK(hipGetLastError());
-  HIP_OK(hipDeviceSynchronize());
+  hipError_t e = hipMalloc(&h->rec, B * REC_BYTES);
+  if (e == hipSuccess) e = hipMalloc(&h->seed, B * 4);
+  if (e == hipSuccess) e = hipMalloc(&h->met, B * sizeof(Metrics));
+  if (e == hipSuccess) e = hipMalloc(&h->errs, 8);
+  if (e == hipSuccess) e = hipMemcpy(h->errs, init, 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(big_init_kernel, dim3(blocks(p.B)), dim3(TB), 0, 0, p, h->rec, h->seed, h->met, (long long)cfg->env_index_base);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {                                          // nothing of a failed creation survives
+    SFX(dcd_big_destroy)(h);
+    return dcd::fail("dcd_mg_create: %zu envs of %d bytes: %s", B, REC_BYTES, hipGetErrorString(e));
+  }
   *out = h;
   return 0;
 }

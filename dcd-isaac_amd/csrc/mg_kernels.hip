@@ -572,10 +572,10 @@ struct DcdMg {
   DcdMgConfig cfg;
   Params p;
   int device;
-  uint8_t* rec;
-  uint32_t* seed;
-  Metrics* met;
-  uint32_t* errs;      // [0] bits, [1] first env
+  uint8_t* rec = nullptr;
+  uint32_t* seed = nullptr;
+  Metrics* met = nullptr;
+  uint32_t* errs = nullptr;      // [0] bits, [1] first env
   unsigned long long* stamps = nullptr;   // diagnostic build only
   // per-launch event pairs while profiling (dcd_mg_profile_begin/end)
   std::vector<hipEvent_t> ev;
@@ -653,16 +653,22 @@ int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out) {
   p.fixed_environment = cfg->fixed_environment; p.goal_noise = cfg->goal_noise; p.engine_seed = cfg->engine_seed;
   p.see_through_walls = cfg->see_through_walls != 0;
   const size_t B = (size_t)p.B;
-  if (hipMalloc(&h->rec, B * REC_BYTES) != hipSuccess || hipMalloc(&h->seed, B * 4) != hipSuccess ||
-      hipMalloc(&h->met, B * sizeof(Metrics)) != hipSuccess || hipMalloc(&h->errs, 8) != hipSuccess) {
-    delete h; return dcd::fail("hipMalloc failed for %zu envs", B);
-  }
   const uint32_t init[2] = {0u, 0x7fffffffu};
-  HIP_OK(hipMemcpy(h->errs, init, 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(init_records_kernel, dim3((p.B + 63) / 64), dim3(64), 0, 0, p, h->rec, h->seed, h->met,
-                     (long long)cfg->env_index_base);
-  HIP_OK(hipGetLastError());
-  HIP_OK(hipDeviceSynchronize());
+  hipError_t e = hipMalloc(&h->rec, B * REC_BYTES);
+  if (e == hipSuccess) e = hipMalloc(&h->seed, B * 4);
+  if (e == hipSuccess) e = hipMalloc(&h->met, B * sizeof(Metrics));
+  if (e == hipSuccess) e = hipMalloc(&h->errs, 8);
+  if (e == hipSuccess) e = hipMemcpy(h->errs, init, 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(init_records_kernel, dim3((p.B + 63) / 64), dim3(64), 0, 0, p, h->rec, h->seed, h->met,
+                       (long long)cfg->env_index_base);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {                                          // nothing of a failed creation survives
+    dcd_mg_destroy(h);
+    return dcd::fail("dcd_mg_create: %zu envs: %s", B, hipGetErrorString(e));
+  }
   *out = h;
   return 0;
 }
@@ -683,6 +689,7 @@ int dcd_mg_destroy(DcdMg* h) {
 
 int dcd_mg_set_seed(DcdMg* h, const int64_t* seeds, void* stream) {
   CHECK_H(h);
+  if (!seeds) return dcd::fail("dcd_mg_set_seed: null seeds");
   if (h->big) return BIG(h, dcd_big_set_seed, seeds, stream);
   hipLaunchKernelGGL(set_seed_kernel, dim3((h->p.B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->rec, h->seed, seeds, h->p.B);
   HIP_OK(hipGetLastError());
