@@ -522,7 +522,13 @@ class AdversarialRunner:
             env_return = scans.env_return(agent_info["mean_return"], agent_info["max_return"], adv["mean_return"],
                                           adv["max_return"], mode=mode)
         if args.adv_normalize_returns:
-            self.env_return_rms.update(env_return.flatten().cpu().numpy())
+            sample = env_return.flatten()
+            if self.world_size > 1:                 # moments of the whole job's batch, in global env order
+                import torch.distributed as dist
+                parts = [torch.empty_like(sample) for _ in range(self.world_size)]
+                dist.all_gather(parts, sample.contiguous(), group=self.process_group)
+                sample = torch.cat(parts)
+            self.env_return_rms.update(sample.cpu().numpy())
             env_return = env_return / float(np.sqrt(self.env_return_rms.var + 1e-8))
         if args.adv_clip_reward is not None:
             env_return = env_return.clamp(-args.adv_clip_reward, args.adv_clip_reward)

@@ -130,3 +130,58 @@ def test_gathered_records_feed_one_sampler():
         b.update_with_records(part, actor_offset=4 * r)            # global actor = rank * B + local actor
     assert np.array_equal(a.seed_scores, b.seed_scores) and np.array_equal(a.partial_seed_scores, b.partial_seed_scores)
     assert np.array_equal(a.partial_seed_steps, b.partial_seed_steps)
+
+
+def _paired_regret(mean, mx, adv_mean, adv_max, mode=0):
+    """Host stand-in for the HIP env-return kernel (PAIRED: max antagonist return - mean protagonist return, >= 0)."""
+    return (adv_max - mean).clamp(min=0).unsqueeze(-1)
+
+
+def _teacher_return(runner_cls, info, adv_info, world, group, updates):
+    import types
+    from dcd_hip import scans
+    from envs.runners.adversarial_runner import RunningMeanStd
+    args = types.SimpleNamespace(ued_algo="paired", adv_normalize_returns=True, adv_clip_reward=None)
+    me = types.SimpleNamespace(args=args, is_paired=True, world_size=world, process_group=group, env_return_rms=RunningMeanStd(shape=()))
+    keep, scans.env_return = scans.env_return, _paired_regret        # collective logic only: no GPU in this test
+    try:
+        for u in range(updates):
+            out = runner_cls._compute_env_return(me, {k: v + u for k, v in info.items()}, {k: v * (1 + u) for k, v in adv_info.items()})
+    finally:
+        scans.env_return = keep
+    return out, me.env_return_rms
+
+
+def _infos(envs):
+    gen = torch.Generator().manual_seed(7)
+    full = {k: torch.rand(8, generator=gen) for k in ("mean_return", "max_return", "adv_mean", "adv_max")}
+    return ({"mean_return": full["mean_return"][envs], "max_return": full["max_return"][envs]},
+            {"mean_return": full["adv_mean"][envs], "max_return": full["adv_max"][envs] + 0.5})
+
+
+def _rms_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    from envs.runners.adversarial_runner import AdversarialRunner
+    envs = list(range(4)) if rank == 0 else list(range(4, 8))
+    ret, rms = _teacher_return(AdversarialRunner, *_infos(envs), world, dist.group.WORLD, updates=3)
+    parts = [torch.empty_like(ret) for _ in range(world)]
+    dist.all_gather(parts, ret)
+    if rank == 0:
+        torch.save({"ret": torch.cat(parts), "mean": float(rms.mean), "var": float(rms.var), "count": float(rms.count)}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_adv_normalize_returns_uses_job_wide_moments():
+    """the teacher-return RMS (adversarial_runner.py:666-668) over 2 ranks x 4 envs == one process, 8 envs."""
+    for p in (ROOT, os.path.join(ROOT, "dcd-isaac_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from envs.runners.adversarial_runner import AdversarialRunner
+    want, rms = _teacher_return(AdversarialRunner, *_infos(list(range(8))), 1, None, updates=3)
+    with tempfile.TemporaryDirectory() as dd:
+        out = os.path.join(dd, "rms.pt")
+        mp.spawn(_rms_worker, args=(2, 29537, out), nprocs=2, join=True)
+        got = torch.load(out, weights_only=True)
+    assert got["mean"] == float(rms.mean) and got["var"] == float(rms.var) and got["count"] == float(rms.count)
+    assert torch.equal(got["ret"], want)
