@@ -15,6 +15,7 @@ Host decisions that the reference takes inside the step loop (PLR per-episode le
 :551-558) still need the done mask on the host and therefore synchronise once per step in replay
 rollouts; PAIRED / DR / non-replay rollouts are sync-free until the rollout ends.
 """
+import os
 from collections import defaultdict, deque
 
 import numpy as np
@@ -58,6 +59,8 @@ class AdversarialRunner:
             self.world_size = dist.get_world_size(process_group)
         self.venv = venv
         self.ued_venv = venv if ued_venv is None else ued_venv
+        self._pending_updates, self._update_streams = [], []
+        self._concurrent_updates = (self.world_size == 1 and os.environ.get("DCD_CONCURRENT_PPO", "1") != "0")
         self.is_discrete_actions = is_discrete_actions(self.venv)
         self.is_discrete_adversary_env_actions = is_discrete_actions(self.venv, adversary=True)
         self.agents = {"agent": agent, "adversary_agent": adversary_agent, "adversary_env": adversary_env}
@@ -119,7 +122,6 @@ class AdversarialRunner:
         # replayed: 17.9 -> 15.5 ms per 256-step rollout at B = 4096.  =2 also captures rollouts whose policy runs
         # as PyTorch modules (teacher, unsupported nets: ~45 nodes per step; capture took minutes on ROCm 7.2).
         # =0: always eager.  Replay rollouts that re-sample levels on the host per step always stay eager.
-        import os
         mode = os.environ.get("DCD_HIP_GRAPHS", "1")
         self.use_hip_graphs = mode in ("1", "2") and self.device.type == "cuda"
         self.graph_pytorch_nets = mode == "2"       # also capture rollouts whose policy runs as PyTorch modules
@@ -483,6 +485,8 @@ class AdversarialRunner:
             return {}
 
         rollout_info = {}
+        if any(a is agent for a, _, _ in self._pending_updates):          # ACCEL: the same student acts again -> new weights first
+            self._flush_updates()
         if level_sampler and level_replay:
             rollout_info["solved_idx"] = np.zeros(B, dtype=bool)
         self._student_rollout(agent, num_steps, level_replay, level_sampler, rollout_info)
@@ -502,14 +506,64 @@ class AdversarialRunner:
                     signed=False, positive_only=False, clipped=clipped, batched=True)
             if level_sampler and update_level_sampler:
                 level_sampler.update_with_rollouts(st)
-            value_loss, action_loss, dist_entropy, info = agent.update(discard_grad=discard_grad)
+            self._submit_update(agent, rollout_info, discard_grad=discard_grad)
             if level_sampler and update_level_sampler:
-                level_sampler.after_update()
-            rollout_info.update({"value_loss": value_loss, "action_loss": action_loss, "dist_entropy": dist_entropy,
-                                 "update_info": info})
+                level_sampler.after_update()                              # sampler bookkeeping: independent of the PPO result
             if args.log_action_complexity:
                 rollout_info["action_complexity"] = st.get_action_complexity()
         return rollout_info
+
+    # ---- PPO updates of one run(): independent of each other, issued together ---------------------------------
+    def _submit_update(self, agent, info, discard_grad=False):
+        """`agent.update()` (adversarial_runner.py:600-606,810-812) with its losses written into `info`.  The
+        protagonist's, the antagonist's and the teacher's updates of one run() touch disjoint networks and storages,
+        and nothing between a student's rollout and the end of run() reads a student's new weights (ACCEL's second
+        rollout does: agent_rollout flushes first).  With DCD_CONCURRENT_PPO=1 (default) on one GPU they are therefore
+        queued here and issued together by `_flush_updates`, each from its own host thread on its own stream: one
+        update is a serial chain of small GEMMs and pointwise kernels (the LSTM recurrence), and three independent
+        chains fill the machine better than one (measured: 680 -> 567 ms for the three PAIRED updates).  With several
+        ranks the updates stay in program order: their gradient all-reduces must be issued in the same order on
+        every rank."""
+        self._pending_updates.append((agent, info, discard_grad))
+        if not self._concurrent_updates:
+            self._flush_updates()
+
+    def _flush_updates(self):
+        jobs, self._pending_updates = self._pending_updates, []
+        if not jobs:
+            return
+
+        def one(agent, info, discard_grad):
+            v, a, e, extra = agent.update(discard_grad=discard_grad)
+            info.update({"value_loss": v, "action_loss": a, "dist_entropy": e, "update_info": extra})
+
+        if len(jobs) == 1 or self.device.type != "cuda":
+            for job in jobs:
+                one(*job)
+            return
+        import threading
+        main = torch.cuda.current_stream(self.device)
+        errors = []
+
+        def work(job, stream):
+            try:
+                stream.wait_stream(main)                                  # rollouts, returns: produced on the caller's stream
+                with torch.cuda.stream(stream):
+                    one(*job)
+            except BaseException as exc:                                  # re-raised on the caller's thread
+                errors.append(exc)
+
+        while len(self._update_streams) < len(jobs):
+            self._update_streams.append(torch.cuda.Stream(self.device))
+        threads = [threading.Thread(target=work, args=(job, st)) for job, st in zip(jobs, self._update_streams)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for st in self._update_streams[:len(jobs)]:
+            main.wait_stream(st)
+        if errors:
+            raise errors[0]
 
     def _compute_env_return(self, agent_info, adversary_agent_info):
         """Teacher's final return: the regret (:637-674), on device."""
@@ -603,8 +657,8 @@ class AdversarialRunner:
                                                      st.masks[-1]).detach()
             st.replace_final_return(env_return)
             st.compute_returns(next_value, args.use_gae, args.gamma, args.gae_lambda)
-            v, a, e, info = adversary_env.update()
-            adversary_env_info.update({"action_loss": a, "value_loss": v, "dist_entropy": e, "update_info": info})
+            self._submit_update(adversary_env, adversary_env_info)
+        self._flush_updates()
         if self.is_training:
             self.num_updates += 1
 

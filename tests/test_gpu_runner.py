@@ -244,3 +244,30 @@ def test_graph_replayed_rollouts_equal_eager_rollouts(monkeypatch):
             assert torch.equal(a[n], b[n]), (k, n)
     assert not torch.equal(results["1"][0]["actions"], results["1"][1]["actions"])     # fresh draws per rollout
     assert not torch.equal(results["1"][2]["actions"], results["1"][3]["actions"])
+
+
+def test_concurrent_ppo_updates_match_in_order_updates(monkeypatch):
+    """The three PPO updates of a PAIRED run() are independent and are issued together from three host threads on three
+    streams (DCD_CONCURRENT_PPO=1, default); =0 issues them in the reference's program order.  Same seeds, both
+    settings: identical rollouts in the first run(), and after two run()s the same weights and losses up to the
+    run-to-run noise of one update (atomics in the weight-gradient reductions: ~1e-4 on the weights either way)."""
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DCD_CONCURRENT_PPO", mode)
+        args = make_args(ued_algo="paired", ppo_epoch=2, adv_ppo_epoch=2)
+        runner, venv = build(args)
+        assert runner._concurrent_updates == (mode == "1")
+        stats = [runner.run() for _ in range(2)]
+        assert not runner._pending_updates
+        out[mode] = (stats, {n: {k: v.clone() for k, v in a.algo.actor_critic.state_dict().items()} for n, a in runner.agents.items()},
+                     runner.agents["agent"].storage.actions.clone())
+        venv.close()
+    (s0, w0, a0), (s1, w1, a1) = out["0"], out["1"]
+    assert s0[0]["mean_env_return"] == s1[0]["mean_env_return"] and s0[0]["total_episodes"] == s1[0]["total_episodes"]
+    for k in ("agent_value_loss", "adversary_value_loss", "adversary_env_value_loss", "agent_pg_loss", "adversary_env_pg_loss",
+              "agent_grad_norm", "adversary_grad_norm", "adversary_env_grad_norm"):
+        assert np.isfinite(s1[0][k]) and s1[0][k] != 0
+        np.testing.assert_allclose(s1[0][k], s0[0][k], rtol=2e-3, atol=1e-6, err_msg=k)
+    for n in w0:
+        for k in w0[n]:
+            torch.testing.assert_close(w1[n][k], w0[n][k], rtol=0, atol=2e-3, msg=f"{n}.{k}")
