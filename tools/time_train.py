@@ -31,7 +31,7 @@ print(json.dumps({"S_roll_steps_per_s": B * 256 / dt, "student_rollout_ms": dt *
 if os.environ.get("ROLLOUT_ONLY"): sys.exit(0)
 sync(); t = time.perf_counter(); runner._teacher_rollout(teacher, 27); sync(); print("teacher rollout ms", (time.perf_counter() - t) * 1e3)
 runner.train(); runner.is_training = True
-for j in range(2):
+for j in range(int(os.environ.get("N_UPDATES", "2"))):
     sync(); t = time.perf_counter(); stats = runner.run(); sync(); dt = time.perf_counter() - t
     print(json.dumps({"update": j, "run_s": dt, "S_train_sps_reference_formula": B * 256 / dt, "true_steps_per_s": (2 * B * 256 + B * 27) / dt,
                       "agent_value_loss": stats["agent_value_loss"], "mean_env_return": stats["mean_env_return"]}))
