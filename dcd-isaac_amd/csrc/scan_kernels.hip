@@ -165,16 +165,16 @@ struct ScoreArgs {
 // whenever masks[t+1] == 0.  Same accumulation order as oracle/scan_oracle.c -> bit-identical records.
 // score functions: level_sampler.py:275-349, 426-439.
 struct SegAcc {
-  double acc, rs; float mx, mn; float r0, v0; int start;
+  double acc, rs; float mx, mn; float r0, v0; int start; int seed;
   __device__ __forceinline__ void reset(int s) { acc = 0.0; rs = 0.0; mx = -INFINITY; mn = INFINITY; r0 = 0.f; v0 = 0.f; start = s; }
 };
 
-template <int ST>
+template <int ST, bool HAVE_SEED = false>
 __device__ __forceinline__ void flush_segment(const ScoreArgs& a, int b, SegAcc& sg, int end, int flags, int& k) {
   const int L = end - sg.start; constexpr int st = ST;
   if (k < a.max_recs) {
     DcdEpisodeRec r;
-    r.actor = b; r.seed = a.seeds[(size_t)sg.start * a.B + b]; r.start_t = sg.start; r.num_steps = L; r.flags = flags;
+    r.actor = b; r.seed = HAVE_SEED ? sg.seed : a.seeds[(size_t)sg.start * a.B + b]; r.start_t = sg.start; r.num_steps = L; r.flags = flags;
     r.reward_sum = (float)sg.rs;
     if (st == DCD_SCORE_UNIFORM) { r.mean_score = 1.f; r.max_score = 1.f; }
     else if (st == DCD_SCORE_RETURN_SUM) { r.mean_score = 0.f; r.max_score = 0.f; }
@@ -244,6 +244,149 @@ __global__ void __launch_bounds__(SCAN_BLOCK) seg_score_kernel(ScoreArgs a) {
     }
   }
   if (sg.start < T) flush_segment<ST>(a, b, sg, T, 0, k);        // trailing partial segment (:551-578)
+}
+
+// ---- the same segmentation and scoring with the rollout staged in LDS ------------------------------------------
+// One env per lane bounds a scan by its loads: a wave holds at most 63 loads in flight, so 256 steps of 5 arrays are
+// 16+ dependent HBM round trips (37 us at B = 4096).  Here a 512-thread workgroup owns SE = 32 envs: every thread
+// issues its share of a [<= 256 steps] x [32 envs] tile of all six arrays at once (24 x 16-byte loads per thread, ONE
+// round trip), the tile is committed to LDS, and 32 lanes run the unchanged sequential pass from LDS.  Segment counts
+// come from a time-parallel count (a segment starts at t = 0 and after every masks[t] == 0, 1 <= t < T), record
+// offsets from per-32-env block sums that every workgroup adds up itself — no single-workgroup scan launch.
+constexpr int SE = 32;            // envs per workgroup (one 128-byte line per row of a tile)
+constexpr int SNT = 512;          // threads per workgroup
+constexpr int STILE = 256;        // time steps per LDS tile
+constexpr int SWEEPS = STILE / (SNT / (SE / 4));   // rows a thread loads per array and tile (8)
+
+// counts[b] = 1 + #{t in [1, T) : masks[t][b] == 0}; block_sums[b / 32] = sum of counts over the 32-env block.
+// Workgroup = 64 envs x 4 time quarters (one wave each), every wave's loads in flight together.
+__global__ void __launch_bounds__(256) seg_count_par_kernel(const float* __restrict__ msk, int T, int B, int* __restrict__ counts,
+                                                            int* __restrict__ block_sums) {
+  __shared__ int part[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + lane;
+  const int per = (T - 1 + 3) / 4, t_lo = 1 + q * per, t_hi = min(t_lo + per, T);
+  int n = 0;
+  if (b < B) {
+    for (int t0 = t_lo; t0 < t_hi; t0 += UNROLL) {
+      float m[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) m[u] = msk[(size_t)min(t0 + u, T) * B + b];     // clamped: loads stay unconditional
+      LOADS_ISSUED();
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) if (t0 + u < t_hi && !(m[u] > 0.f)) ++n;
+    }
+  }
+  part[q][lane] = n;
+  __syncthreads();
+  if (q == 0) {
+    n = (b < B) ? part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane] + 1 : 0;
+    if (b < B) counts[b] = n;
+    int sum = n;
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);                 // within each half-wave of 32
+    if ((lane & 31) == 0 && blockIdx.x * 64 + lane < B) block_sums[(blockIdx.x * 64 + lane) >> 5] = sum;
+  }
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));     // a plain vector: arrays of it stay in registers
+
+template <int ST>
+__global__ void __launch_bounds__(SNT) seg_score_lds_kernel(ScoreArgs a, const int* __restrict__ counts,
+                                                            const int* __restrict__ block_sums, int* __restrict__ n_recs) {
+  __shared__ __attribute__((aligned(16))) float s_rew[STILE][SE];
+  __shared__ __attribute__((aligned(16))) float s_ret[STILE][SE];
+  __shared__ __attribute__((aligned(16))) float s_val[STILE][SE];     // value_preds[t + 1]
+  __shared__ __attribute__((aligned(16))) int s_seed[STILE][SE];
+  __shared__ __attribute__((aligned(16))) uint8_t s_flag[STILE][SE];  // bit 0: masks[t + 1] > 0, bit 1: cliffhanger[t + 1] > 0
+  __shared__ int s_part[SNT / 64];
+  constexpr int st = ST;
+  constexpr bool use_ret = st <= DCD_SCORE_SIGNED_VALUE_LOSS, use_val = use_ret || st == DCD_SCORE_ONE_STEP_TD;
+  const int tid = threadIdx.x, lane = tid & 63, T = a.T, B = a.B;
+  const int b0 = blockIdx.x * SE;                          // B % SE == 0 on this path (checked by the launcher)
+  // ---- record offset of this block = sum of the block sums before it; of a lane = + exclusive scan of its block's counts
+  int acc = 0;
+  for (int j = tid; j < (int)blockIdx.x; j += SNT) acc += block_sums[j];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) s_part[tid >> 6] = acc;
+  int cnt = 0, k = 0;
+  float vnext = 0.f;
+  if (tid < SE) { cnt = counts[b0 + tid]; if (use_val) vnext = a.val[b0 + tid]; }
+  __syncthreads();
+  if (tid < 64) {
+    int x = (tid < SE) ? cnt : 0;
+#pragma unroll
+    for (int off = 1; off < SE; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < SNT / 64; ++w) base += s_part[w];
+    k = base + x - cnt;
+    if (blockIdx.x == gridDim.x - 1 && tid == SE - 1) n_recs[0] = base + x;
+  }
+  SegAcc sg; sg.reset(0);
+  const int c4 = tid & 7, rr = tid >> 3;                   // this thread's 4-env column group and first row of a sweep
+  for (int t0 = 0; t0 < T; t0 += STILE) {
+    const int rows = min(STILE, T - t0);
+    {
+      u32x4 q_rew[SWEEPS], q_ret[SWEEPS], q_val[SWEEPS], q_seed[SWEEPS], q_msk[SWEEPS], q_cl[SWEEPS];
+#pragma unroll
+      for (int w = 0; w < SWEEPS; ++w) {
+        const int r = min(w * (SNT / 8) + rr, rows - 1);   // clamped: loads stay unconditional
+        const size_t o0 = (size_t)(t0 + r) * B + b0 + c4 * 4, o1 = o0 + B;
+        q_rew[w] = *reinterpret_cast<const u32x4*>(a.rew + o0);
+        q_seed[w] = *reinterpret_cast<const u32x4*>(a.seeds + o0);
+        q_msk[w] = *reinterpret_cast<const u32x4*>(a.msk + o1);
+        q_cl[w] = *reinterpret_cast<const u32x4*>(a.cliff + o1);
+        if (use_ret) q_ret[w] = *reinterpret_cast<const u32x4*>(a.ret + o0);
+        if (use_val) q_val[w] = *reinterpret_cast<const u32x4*>(a.val + o1);
+      }
+      LOADS_ISSUED();
+      if (t0 > 0) __syncthreads();                         // the previous tile has been consumed
+#pragma unroll
+      for (int w = 0; w < SWEEPS; ++w) {
+        const int r = w * (SNT / 8) + rr;                  // rows beyond the tile hold copies of its last row, never read
+        {
+          *reinterpret_cast<u32x4*>(&s_rew[r][c4 * 4]) = q_rew[w];
+          *reinterpret_cast<u32x4*>(&s_seed[r][c4 * 4]) = q_seed[w];
+          if (use_ret) *reinterpret_cast<u32x4*>(&s_ret[r][c4 * 4]) = q_ret[w];
+          if (use_val) *reinterpret_cast<u32x4*>(&s_val[r][c4 * 4]) = q_val[w];
+          const uint32_t mm[4] = {q_msk[w].x, q_msk[w].y, q_msk[w].z, q_msk[w].w}, cc[4] = {q_cl[w].x, q_cl[w].y, q_cl[w].z, q_cl[w].w};
+          uint32_t f = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            f |= (uint32_t)((__uint_as_float(mm[e]) > 0.f ? 1u : 0u) | (__uint_as_float(cc[e]) > 0.f ? 2u : 0u)) << (8 * e);
+          *reinterpret_cast<uint32_t*>(&s_flag[r][c4 * 4]) = f;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < SE) {
+      const int b = b0 + tid;
+#pragma unroll 8
+      for (int r = 0; r < rows; ++r) {
+        const int t = t0 + r;
+        if (sg.start < T) {
+          const float v0 = vnext, rw = s_rew[r][tid];
+          const uint32_t fl = s_flag[r][tid];
+          const bool seg_ends = !(fl & 1u);
+          const bool last_in_seg = seg_ends || t == T - 1;
+          sg.rs += (double)rw;
+          if (t == sg.start) { sg.r0 = rw; sg.v0 = v0; sg.seed = s_seed[r][tid]; }
+          if (use_ret) {
+            float adv = s_ret[r][tid] - v0;
+            if (st == DCD_SCORE_VALUE_L1) adv = fabsf(adv); else if (st == DCD_SCORE_POSITIVE_VALUE_LOSS) adv = adv > 0.f ? adv : 0.f;
+            sg.acc += adv; sg.mx = adv > sg.mx ? adv : sg.mx;
+          } else if (st == DCD_SCORE_ONE_STEP_TD) {
+            if (!last_in_seg) { const float td = fabsf((rw + (a.g * s_val[r][tid])) - v0); sg.acc += td; sg.mx = td > sg.mx ? td : sg.mx; }
+          }
+          if (seg_ends) { flush_segment<ST, true>(a, b, sg, t + 1, 1 | ((fl & 2u) ? 0 : 2), k); sg.reset(t + 1); }
+        }
+        if (use_val) vnext = s_val[r][tid];
+      }
+    }
+  }
+  if (tid < SE && sg.start < T) flush_segment<ST, true>(a, b0 + tid, sg, T, 0, k);     // trailing partial segment (:551-578)
 }
 
 // grounded_* strategies (level_sampler.py:351-424), one lane per record
@@ -343,6 +486,24 @@ int dcd_episode_scores(const float* returns, const float* value_preds, const flo
   if (needs_returns && !returns) return dcd::fail("dcd_episode_scores: strategy %d needs returns", strategy);
   int* counts = workspace; int* offsets = workspace + B;
   hipStream_t s = (hipStream_t)stream;
+  auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+  const bool vec_ok = aligned16(rewards) && aligned16(masks) && aligned16(cliffhanger_masks) && aligned16(level_seeds) &&
+                      aligned16(value_preds) && (!needs_returns || aligned16(returns));
+  if (!needs_logits && vec_ok && B % SE == 0 && B <= (1 << 18)) {     // staged path: [T, 32-env] tiles in LDS, 2 launches
+    int* block_sums = offsets;
+    ScoreArgs a;
+    a.ret = returns; a.val = value_preds; a.rew = rewards; a.msk = masks; a.cliff = cliffhanger_masks; a.logits = nullptr;
+    a.seeds = level_seeds; a.T = T; a.B = B; a.A = A; a.strategy = strategy; a.g = (float)gamma; a.recs = recs; a.max_recs = max_recs;
+    a.offsets = nullptr;
+    hipLaunchKernelGGL(seg_count_par_kernel, dim3((B + 63) / 64), dim3(256), 0, s, masks, T, B, counts, block_sums);
+    switch (strategy) {
+#define DCD_SCORE_CASE(ST) case ST: hipLaunchKernelGGL(seg_score_lds_kernel<ST>, dim3(B / SE), dim3(SNT), 0, s, a, (const int*)counts, (const int*)block_sums, n_recs); break;
+      DCD_SCORE_CASE(0) DCD_SCORE_CASE(1) DCD_SCORE_CASE(2) DCD_SCORE_CASE(6) DCD_SCORE_CASE(7) DCD_SCORE_CASE(8)
+#undef DCD_SCORE_CASE
+    }
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(seg_count_kernel, dim3(nblk(B)), dim3(SCAN_BLOCK), 0, s, masks, T, B, counts);
   hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, counts, offsets, B, n_recs);
   ScoreArgs a;

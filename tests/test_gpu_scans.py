@@ -142,6 +142,31 @@ def test_episode_scores_full_size_match_oracle(strategy):
         assert np.array_equal(bits(mean.cpu().numpy()), bits(rm)) and np.array_equal(bits(mx.cpu().numpy()), bits(rx))
 
 
+@pytest.mark.parametrize("T,B", [(37, 32), (256, 96), (300, 64), (513, 160), (40, 77)])
+@pytest.mark.parametrize("strategy", [1, 6, 8])
+def test_episode_scores_staged_path_shapes(strategy, T, B):
+    """The LDS-staged scoring path (B a multiple of 32) over one, two and three time tiles, partial tiles, blocks that
+    span several count workgroups, and (B = 77) the one-env-per-lane path it falls back to; a done on the last step or not."""
+    from dcd_hip import scans
+    rng = np.random.default_rng(100 * T + B + strategy)
+    r = (rng.random((T, B)) * (rng.random((T, B)) < 0.05)).astype(np.float32)
+    v = rng.standard_normal((T + 1, B)).astype(np.float32)
+    m = (rng.random((T + 1, B)) < 0.9).astype(np.float32)
+    m[T][rng.random(B) < 0.5] = 0
+    R = (v + 0.3 * rng.standard_normal(v.shape)).astype(np.float32)
+    cliff = (rng.random((T + 1, B)) < 0.7).astype(np.float32)
+    seeds = rng.integers(1, 5000, (T, B)).astype(np.int32)
+    sc = scans.EpisodeScorer(T, B, DEV)
+    sc.launch(dev(R), dev(v), dev(r), dev(m), dev(cliff), dev(seeds), None, strategy, 0.995)
+    recs = sc.records()
+    ref = orc.episode_scores(R, v, r, m, cliff, seeds, None, strategy, 0.995)
+    assert len(recs) == len(ref)
+    for k in ("actor", "seed", "start_t", "num_steps", "flags"):
+        assert np.array_equal(recs[k], ref[k]), k
+    for k in ("mean_score", "max_score", "reward_sum"):
+        assert np.array_equal(bits(recs[k]), bits(ref[k])), k
+
+
 def test_return_stats_and_regret_match_oracle():
     from dcd_hip import scans
     rng = np.random.default_rng(9)
