@@ -407,18 +407,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
   __shared__ Luts lut;
   const int tid = threadIdx.x, row0 = blockIdx.x * EPB;
   const int n = min(EPB, n_rows_in - row0), row = row0 + tid;
-  // per-env operands of the logic lane, requested before the record staging is waited for (one HBM round trip, not two)
-  uint32_t pre_seed = 0; Metrics pre_m = {0, 0, 0, 0}; int64_t pre_loc = 0;
-  int my_env = -1;
-  if (tid < EPB) {
-    my_env = (tid < n) ? (idx_in ? idx_in[row] : row) : -1;
-    env_of[tid] = my_env;
-    if (my_env >= 0 && OP != OP_READ_ENC) {
-      pre_seed = a.seed[my_env];
-      pre_m = a.met[my_env];
-      if (OP == OP_STEP_ADV) pre_loc = a.loc[my_env];
-    }
-  }
+  if (tid < EPB) env_of[tid] = (tid < n) ? (idx_in ? idx_in[row] : row) : -1;
   const int S = p.S;
   init_luts(lut, tid);
   __syncthreads();
@@ -431,16 +420,16 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
 
   constexpr bool ADV_OUT = (OP == OP_RESET || OP == OP_STEP_ADV || OP == OP_READ_ENC);
   if (tid < n && OP != OP_READ_ENC) {
-    const int env = my_env;
-    Env e = make_env(as_lds(lds + tid * LP), pre_seed);
-    Metrics m = pre_m;
+    const int env = env_of[tid];
+    Env e = make_env(as_lds(lds + tid * LP), a.seed[env]);
+    Metrics m = a.met[env];
     bool done = false;
     if (OP == OP_RESET) {
       env_reset(e, p, m, nullptr);                  // random_z floats are produced cooperatively below
       e.elapsed = 0;                                // TimeLimit.reset (time_limit.py:35-37)
       e.ep_ret = 0.f; e.ep_len = 0;                 // VecMonitor.reset (vec_monitor.py:36-40)
     } else if (OP == OP_STEP_ADV) {
-      done = env_step_adversary(e, p, m, pre_loc, nullptr);
+      done = env_step_adversary(e, p, m, a.loc[env], nullptr);
     } else if (OP == OP_RESET_AGENT) {
       reset_agent(e);
       e.elapsed = 0;                                // time_limit.py:47-49

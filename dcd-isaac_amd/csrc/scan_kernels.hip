@@ -289,6 +289,42 @@ __global__ void __launch_bounds__(256) seg_count_par_kernel(const float* __restr
   }
 }
 
+// The staged kernel's sequential lanes only PARK a finished segment in its record slot (sums as accumulated, no
+// division): a flush is divergent — the whole wave walks through it whenever one lane closes a segment — and the
+// fp64 division in it cost more than the scan itself (38 us of 256 steps at B = 4096 went there).  All threads of the
+// workgroup then turn the parked slots of their block into records (same expressions as flush_segment, bit for bit).
+struct RawRec { int32_t actor, seed, start_t, len_flags; double acc; float reward_sum, mx; };   // 32 bytes, as DcdEpisodeRec
+static_assert(sizeof(RawRec) == sizeof(DcdEpisodeRec), "raw slot must overlay the record");
+constexpr int RAW_LEN_BITS = 24;                         // len_flags = L | flags << 24 | single-step-TD << 30
+
+template <int ST>
+__device__ __forceinline__ void park_segment(const ScoreArgs& a, int b, const SegAcc& sg, int end, int flags, int& k) {
+  const int L = end - sg.start;
+  if (k < a.max_recs) {
+    RawRec r;
+    r.actor = b; r.seed = sg.seed; r.start_t = sg.start; r.len_flags = L | (flags << RAW_LEN_BITS);
+    r.acc = sg.acc; r.mx = sg.mx; r.reward_sum = (float)sg.rs;
+    if (ST == DCD_SCORE_ONE_STEP_TD && L <= 1) { r.acc = (double)(sg.r0 - sg.v0); r.len_flags |= 1 << 30; }   // signed (:433)
+    *reinterpret_cast<RawRec*>(a.recs + k) = r;
+  }
+  ++k;
+}
+template <int ST>
+__device__ __forceinline__ void finish_record(DcdEpisodeRec* slot) {
+  const RawRec w = *reinterpret_cast<const RawRec*>(slot);
+  const int L = w.len_flags & ((1 << RAW_LEN_BITS) - 1);
+  DcdEpisodeRec r;
+  r.actor = w.actor; r.seed = w.seed; r.start_t = w.start_t; r.num_steps = L; r.flags = (w.len_flags >> RAW_LEN_BITS) & 3;
+  r.reward_sum = w.reward_sum;
+  if (ST == DCD_SCORE_UNIFORM) { r.mean_score = 1.f; r.max_score = 1.f; }
+  else if (ST == DCD_SCORE_RETURN_SUM) { r.mean_score = 0.f; r.max_score = 0.f; }
+  else if (ST == DCD_SCORE_ONE_STEP_TD) {
+    if (w.len_flags & (1 << 30)) { r.mean_score = (float)w.acc; r.max_score = r.mean_score; }
+    else { r.mean_score = (float)(w.acc / (double)(L - 1)); r.max_score = w.mx; }
+  } else { r.mean_score = (float)(w.acc / (double)L); r.max_score = w.mx; }
+  *slot = r;
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));     // a plain vector: arrays of it stay in registers
 
 template <int ST>
@@ -300,6 +336,7 @@ __global__ void __launch_bounds__(SNT) seg_score_lds_kernel(ScoreArgs a, const i
   __shared__ __attribute__((aligned(16))) int s_seed[STILE][SE];
   __shared__ __attribute__((aligned(16))) uint8_t s_flag[STILE][SE];  // bit 0: masks[t + 1] > 0, bit 1: cliffhanger[t + 1] > 0
   __shared__ int s_part[SNT / 64];
+  __shared__ int s_range[2];
   constexpr int st = ST;
   constexpr bool use_ret = st <= DCD_SCORE_SIGNED_VALUE_LOSS, use_val = use_ret || st == DCD_SCORE_ONE_STEP_TD;
   const int tid = threadIdx.x, lane = tid & 63, T = a.T, B = a.B;
@@ -322,7 +359,7 @@ __global__ void __launch_bounds__(SNT) seg_score_lds_kernel(ScoreArgs a, const i
 #pragma unroll
     for (int w = 0; w < SNT / 64; ++w) base += s_part[w];
     k = base + x - cnt;
-    if (blockIdx.x == gridDim.x - 1 && tid == SE - 1) n_recs[0] = base + x;
+    if (tid == SE - 1) { s_range[0] = base; s_range[1] = base + x; if (blockIdx.x == gridDim.x - 1) n_recs[0] = base + x; }
   }
   SegAcc sg; sg.reset(0);
   const int c4 = tid & 7, rr = tid >> 3;                   // this thread's 4-env column group and first row of a sweep
@@ -363,30 +400,43 @@ __global__ void __launch_bounds__(SNT) seg_score_lds_kernel(ScoreArgs a, const i
     __syncthreads();
     if (tid < SE) {
       const int b = b0 + tid;
-#pragma unroll 8
-      for (int r = 0; r < rows; ++r) {
-        const int t = t0 + r;
-        if (sg.start < T) {
-          const float v0 = vnext, rw = s_rew[r][tid];
-          const uint32_t fl = s_flag[r][tid];
-          const bool seg_ends = !(fl & 1u);
-          const bool last_in_seg = seg_ends || t == T - 1;
-          sg.rs += (double)rw;
-          if (t == sg.start) { sg.r0 = rw; sg.v0 = v0; sg.seed = s_seed[r][tid]; }
-          if (use_ret) {
-            float adv = s_ret[r][tid] - v0;
-            if (st == DCD_SCORE_VALUE_L1) adv = fabsf(adv); else if (st == DCD_SCORE_POSITIVE_VALUE_LOSS) adv = adv > 0.f ? adv : 0.f;
-            sg.acc += adv; sg.mx = adv > sg.mx ? adv : sg.mx;
-          } else if (st == DCD_SCORE_ONE_STEP_TD) {
-            if (!last_in_seg) { const float td = fabsf((rw + (a.g * s_val[r][tid])) - v0); sg.acc += td; sg.mx = td > sg.mx ? td : sg.mx; }
-          }
-          if (seg_ends) { flush_segment<ST, true>(a, b, sg, t + 1, 1 | ((fl & 2u) ? 0 : 2), k); sg.reset(t + 1); }
+      constexpr int CH = 16;                               // steps whose LDS reads are issued ahead of the dependent chain
+      for (int r0 = 0; r0 < rows; r0 += CH) {
+        float rw[CH], rt[CH], vl[CH]; uint32_t fl[CH]; int sd[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int r = min(r0 + u, STILE - 1);            // rows beyond the tile: valid LDS, masked below
+          rw[u] = s_rew[r][tid]; fl[u] = s_flag[r][tid]; sd[u] = s_seed[r][tid];
+          rt[u] = use_ret ? s_ret[r][tid] : 0.f;
+          vl[u] = use_val ? s_val[r][tid] : 0.f;
         }
-        if (use_val) vnext = s_val[r][tid];
+        LOADS_ISSUED();
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int t = t0 + r0 + u;
+          if (r0 + u < rows && sg.start < T) {
+            const float v0 = vnext;
+            const bool seg_ends = !(fl[u] & 1u);
+            const bool last_in_seg = seg_ends || t == T - 1;
+            sg.rs += (double)rw[u];
+            if (t == sg.start) { sg.r0 = rw[u]; sg.v0 = v0; sg.seed = sd[u]; }
+            if (use_ret) {
+              float adv = rt[u] - v0;
+              if (st == DCD_SCORE_VALUE_L1) adv = fabsf(adv); else if (st == DCD_SCORE_POSITIVE_VALUE_LOSS) adv = adv > 0.f ? adv : 0.f;
+              sg.acc += adv; sg.mx = adv > sg.mx ? adv : sg.mx;
+            } else if (st == DCD_SCORE_ONE_STEP_TD) {
+              if (!last_in_seg) { const float td = fabsf((rw[u] + (a.g * vl[u])) - v0); sg.acc += td; sg.mx = td > sg.mx ? td : sg.mx; }
+            }
+            if (seg_ends) { park_segment<ST>(a, b, sg, t + 1, 1 | ((fl[u] & 2u) ? 0 : 2), k); sg.reset(t + 1); }
+          }
+          if (use_val && r0 + u < rows) vnext = vl[u];
+        }
       }
     }
   }
-  if (tid < SE && sg.start < T) flush_segment<ST, true>(a, b0 + tid, sg, T, 0, k);     // trailing partial segment (:551-578)
+  if (tid < SE && sg.start < T) park_segment<ST>(a, b0 + tid, sg, T, 0, k);           // trailing partial segment (:551-578)
+  __syncthreads();                                         // the block's slots [s_range[0], s_range[1]) are parked
+  for (int j = s_range[0] + tid; j < min(s_range[1], a.max_recs); j += SNT) finish_record<ST>(a.recs + j);
 }
 
 // grounded_* strategies (level_sampler.py:351-424), one lane per record
