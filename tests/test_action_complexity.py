@@ -46,3 +46,15 @@ def test_c_action_complexity_equals_python_loop():
         assert got.shape == (B, 1)
         for b in range(B):
             assert abs(got[b, 0].item() - np.float32(np.mean(per[b]))) < 1e-6
+
+
+def test_threaded_action_complexity_equals_single_thread(monkeypatch):
+    """Envs are split over host threads (>= 64 envs each): same totals and per-env values as one thread and as the loop."""
+    st = _storage(40, 331, 7, 5)
+    monkeypatch.setenv("DCD_HOST_THREADS", "1")
+    one, one_env = st.get_action_complexity(), st.get_batched_action_complexity()
+    monkeypatch.setenv("DCD_HOST_THREADS", "5")
+    many, many_env = st.get_action_complexity(), st.get_batched_action_complexity()
+    assert one == many and torch.equal(one_env, many_env)
+    ref, _ = _python_reference(st)
+    assert many == ref
