@@ -383,14 +383,17 @@ class AdversarialRunner:
         st.obs["image"][step + 1][finished] = out["image_f32"]
         st.obs["direction"][step + 1][finished] = out["dir_f32"]
         for i, s in zip(idx, seeds):
-            self._next_level_seeds[i] = s
+            self.current_level_seeds[i] = s                              # this rollout's own copy (_student_rollout)
             rollout_info["solved_idx"][i] = True
+        self._seeds_dev[finished] = torch.tensor(seeds, dtype=torch.int32, device=self.device).view(-1, 1)
 
     def _student_rollout(self, agent, num_steps, level_replay, level_sampler, rollout_info):
         track_seeds = level_sampler is not None
         if track_seeds:
             self._seeds_dev.copy_(torch.tensor(self.current_level_seeds, dtype=torch.int32).view(-1, 1))
         host_resampling = level_sampler is not None and level_replay
+        if host_resampling:                     # per-step re-sampling edits the seed list in place; the list sampled at the
+            self.current_level_seeds = list(self.current_level_seeds)   # start of the rollout stays with its other holders
         fused = self._fused_actor(agent) if self.is_discrete_actions else None
         if fused is not None:
             fused.begin_rollout(num_steps)
@@ -447,10 +450,7 @@ class AdversarialRunner:
             if args.clip_reward:
                 st.rewards[step].clamp_(-args.clip_reward, args.clip_reward)
             if level_sampler is not None and level_replay:
-                self._next_level_seeds = list(self.current_level_seeds)
                 self._resample_finished_levels(st, step, level_sampler, rollout_info)
-                self.current_level_seeds = self._next_level_seeds
-                self._seeds_dev.copy_(torch.tensor(self.current_level_seeds, dtype=torch.int32).view(-1, 1))
             st.advance()
 
     def agent_rollout(self, agent, num_steps, update=False, is_env=False, level_replay=False, level_sampler=None,
