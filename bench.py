@@ -265,7 +265,8 @@ def end_to_end_leg(B, T, device, updates):
     from util import create_parallel_env, make_agent, seed
     a = arg_parser.parse_args([])
     for k, v in dict(env_name="MultiGrid-GoalLastFewerBlocksAdversarial-v0", num_processes=B, num_steps=T, ued_algo="paired",
-                     handle_timelimits=True, recurrent_adversary_env=True, ppo_epoch=5, adv_ppo_epoch=5, num_mini_batch=1).items():
+                     handle_timelimits=True, recurrent_adversary_env=True, ppo_epoch=5, adv_ppo_epoch=5, num_mini_batch=1,
+                     log_action_complexity=True).items():            # as train_scripts/grid_configs/minigrid/25_blocks/mg_25b_paired.json
         setattr(a, k, v)
     seed(1)
     venv, ued = create_parallel_env(a, device=device)
