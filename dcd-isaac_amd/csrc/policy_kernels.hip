@@ -315,6 +315,30 @@ __global__ void __launch_bounds__(LB) lstm_seq_bwd_kernel(const float* __restric
   dcf[q] = dc * f;
 }
 
+// out[r, :] += sum over k < K of y[src[r, k], :] (src < 0: no term), terms added in k order: the scatter side of the
+// teacher's incremental input projection without atomics — every y row is read once, every out row written once,
+// and the result does not depend on scheduling.  Workgroup = one destination row x 256 float4 columns.
+__global__ void __launch_bounds__(256) gather_sum_rows_kernel(const float* __restrict__ y, const int32_t* __restrict__ src,
+                                                              float* __restrict__ out, int K, int G4) {
+  const int r = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= G4) return;
+  const int32_t* s = src + (size_t)r * K;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool any = false;
+  for (int k = 0; k < K; ++k) {
+    const int i = s[k];                                    // wave-uniform
+    if (i < 0) continue;
+    const float4 v = reinterpret_cast<const float4*>(y)[(size_t)i * G4 + c];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    any = true;
+  }
+  if (!any) return;
+  float4* o = reinterpret_cast<float4*>(out) + (size_t)r * G4 + c;
+  float4 w = *o;
+  w.x += acc.x; w.y += acc.y; w.z += acc.z; w.w += acc.w;
+  *o = w;
+}
+
 }  // namespace
 
 extern "C" {
@@ -409,5 +433,14 @@ int dcd_lstm_seq_bwd_step(const float* act, const float* c_t, const float* c_pre
   if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_lstm_seq_bwd_step: launch failed");
   return 0;
 }
+
+int dcd_gather_sum_rows(const float* y, const int32_t* src, float* out, int32_t R, int32_t K, int32_t G, void* stream) {
+  if (!y || !src || !out || R <= 0 || K <= 0 || G <= 0 || (G & 3)) return dcd::fail("dcd_gather_sum_rows: NULL pointer, empty, or G not a multiple of 4");
+  if (((uintptr_t)y | (uintptr_t)out) & 15) return dcd::fail("dcd_gather_sum_rows: y / out must be 16-byte aligned");
+  hipLaunchKernelGGL(gather_sum_rows_kernel, dim3((unsigned)R, (unsigned)((G / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, src, out, K, G / 4);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_gather_sum_rows: launch failed");
+  return 0;
+}
+
 
 }  // extern "C"

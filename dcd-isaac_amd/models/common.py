@@ -146,6 +146,29 @@ def _valid_conv_gemm(self, x):
 Conv2d_tf._valid_conv_gemm = _valid_conv_gemm
 
 
+class GatherSumRows(torch.autograd.Function):
+    """base[r] += sum_k y[src[r, k]] (src < 0: no term) in place, by `dcd_gather_sum_rows`: every y row read once, terms
+    added in k order (no atomics).  `row_of` [len(y)] names the row each y row goes to (any valid row for rows that go
+    nowhere: their gradient is never used) — the backward of the scatter is that gather."""
+
+    @staticmethod
+    def forward(ctx, base, y, src, row_of):
+        import ctypes as C
+        from dcd_hip import check, lib, ptr, stream_ptr
+        R, G = base.shape
+        assert base.is_contiguous() and y.is_contiguous() and src.is_contiguous() and src.dtype == torch.int32 and src.shape[0] == R
+        check(lib().dcd_gather_sum_rows(ptr(y, torch.float32), ptr(src, torch.int32), ptr(base, torch.float32), C.c_int32(R),
+                                        C.c_int32(src.shape[1]), C.c_int32(G), stream_ptr()))
+        ctx.mark_dirty(base)
+        ctx.save_for_backward(row_of)
+        return base
+
+    @staticmethod
+    def backward(ctx, grad):
+        (row_of,) = ctx.saved_tensors
+        return grad, grad.index_select(0, row_of), None, None
+
+
 def _fused_lstm_enabled():
     import os
     return os.environ.get("DCD_FUSED_LSTM", "1") != "0"

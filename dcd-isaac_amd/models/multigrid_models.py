@@ -69,6 +69,7 @@ class MultigridNetwork(DeviceAwareModule):
     # incoming gradient, which turns the two backward GEMMs sparse in the same way).  Exact algebra — results equal the
     # dense path up to fp32 summation order (tests/test_gpu_policy.py); falls back to the dense path when more than
     # `INCREMENTAL_MAX_DENSITY` of the (t, n, p) triples changed.
+    INCREMENTAL_MAX_PADDING = 2.0      # batched form only while the padded [P, cmax] layout is at most this x the triples
     INCREMENTAL_MAX_DENSITY = 0.3
 
     def _incremental_eligible(self, image, n_state):
@@ -97,9 +98,27 @@ class MultigridNetwork(DeviceAwareModule):
                 return None
             p = oy * O + ox
             order = torch.argsort(p, stable=True)                                           # group the triples by position
-            counts = torch.bincount(p, minlength=P).cpu().tolist()                          # (one host sync)
+            counts_dev = torch.bincount(p, minlength=P)
+            counts = counts_dev.cpu().tolist()                                              # (one host sync)
             tt, nn_, oy, ox = tt[order], nn_[order], oy[order], ox[order]
             row_t, row_prev = (tt + 1) * N + nn_, tt * N + nn_
+            cmax = max(counts) if counts else 0
+            batched = M > 0 and cmax * P <= self.INCREMENTAL_MAX_PADDING * M
+            if batched:                                      # slot of triple i in the [P, cmax] padded layout; padding -> row TN
+                starts = torch.cumsum(counts_dev, 0) - counts_dev
+                p_sorted = p[order]
+                slot = p_sorted * cmax + (torch.arange(M, device=image.device) - starts[p_sorted])
+                row_of = torch.zeros((P * cmax,), dtype=torch.long, device=image.device)   # padding -> row 0 (unused grad)
+                row_of[slot] = row_t
+                # src[r, k]: slot of the k-th triple of row r.  nonzero() lists the triples of one (t, n) contiguously:
+                # k = distance to the first triple of the run (left insertion point of the key)
+                key = row_t[torch.argsort(order)]                                          # rows in nonzero() order
+                rank = torch.arange(M, device=image.device) - torch.searchsorted(key, key)  # key is non-decreasing
+                kmax = int(rank.max()) + 1                                                 # (second host sync)
+                src = torch.full((TN, kmax), -1, dtype=torch.int32, device=image.device)
+                slot_u = torch.empty_like(slot)
+                slot_u[order] = slot
+                src[key, rank] = slot_u.to(torch.int32)
             k = torch.arange(3, device=image.device)
             offs = (torch.arange(C, device=image.device).view(C, 1, 1) * S * S + k.view(1, 3, 1) * S + k.view(1, 1, 3)).reshape(-1)
             col = (oy * S + ox).unsqueeze(1) + offs.unsqueeze(0)                            # [M, 27]: the 3x3xC window of each triple
@@ -111,6 +130,16 @@ class MultigridNetwork(DeviceAwareModule):
         if M:
             act = lambda rows: torch.relu(torch.addmm(conv.bias, flat[rows.unsqueeze(1), col], wc.t()))
             delta = act(row_t) - act(row_prev)                                               # [M, F] feature change per triple
+        if M and batched:
+            # One batched GEMM over the positions instead of P small ones (545 launches per epoch, host-bound and at
+            # ~1/3 of the large-GEMM rate): the triples of a position are padded to the longest group (teacher cells
+            # are near-uniform: ~10 % padding), [P, cmax, F] x [P, F, 4H]; each row then sums its <= 18 product rows
+            # in a fixed order (dcd_gather_sum_rows: no atomics; one atomic index_add_ over the 4 GB product took 8 ms).
+            from .common import GatherSumRows
+            dpad = delta.new_zeros((P * cmax, F)).index_copy(0, slot, delta)
+            wp = wf.view(G, F, P).permute(2, 1, 0).contiguous()                              # [P, F, 4H]
+            xp = GatherSumRows.apply(xp, torch.bmm(dpad.view(P, cmax, F), wp).view(P * cmax, G), src, row_of)
+        elif M:
             # unbind / split (ONE backward node each, which stacks / concatenates the pieces' grads): indexing wperm[q]
             # and delta[a:b] inside the loop would make every iteration's backward materialise a full-size zero tensor
             wparts = wf.view(G, F, P).permute(2, 1, 0).contiguous().unbind(0)               # P x [F, 4H]

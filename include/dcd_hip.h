@@ -367,6 +367,12 @@ int dcd_lstm_seq_bwd_step(const float* act, const float* c_t, const float* c_pre
                           const float* dh_last, const float* dc_last, float* dgates, float* dcf, int32_t N,
                           int32_t H, void* stream);
 
+/* Scatter side of the teacher's incremental input projection (no reference counterpart: the reference multiplies the
+ * dense 21 632-wide conv features every step, models/multigrid_models.py:122-138): out[r,:] += sum_k y[src[r,k],:],
+ * src int32[R,K] (negative = no term), terms added in k order; y float[*,G], out float[R,G], G a multiple of 4,
+ * y / out 16-byte aligned. */
+int dcd_gather_sum_rows(const float* y, const int32_t* src, float* out, int32_t R, int32_t K, int32_t G, void* stream);
+
 /* ---- logging statistics (HOST pointers — the only entry point that is not a device call) ------------------ */
 /* RolloutStorage.get_action_complexity / get_batched_action_complexity (algos/storage.py:329-369): LZ76 phrase
  * count (the `lempel_ziv_complexity` package, storage.py:21) of every episode's action string "a0 a1 ...";

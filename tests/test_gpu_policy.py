@@ -229,11 +229,15 @@ def test_incremental_teacher_projection_matches_dense_path(monkeypatch):
         ((v * w).sum() + (lp * w).sum() + ent).backward()
         return [v.detach(), lp.detach(), ent.detach()] + [p.grad.clone() for p in net.parameters()]
 
-    dense, inc = run("0"), run("1")
+    dense, inc = run("0"), run("1")                                  # batched form: one GEMM over the padded positions
+    monkeypatch.setattr(type(net), "INCREMENTAL_MAX_PADDING", 0.0)
+    loop = run("1")                                                  # per-position form (skewed position histograms)
+    monkeypatch.undo()
     names = ["value", "log_prob", "entropy"] + [n for n, _ in net.named_parameters()]
-    for n, a, b in zip(names, dense, inc):
-        scale = max(a.abs().max().item(), 1e-6)
-        assert (a - b).abs().max().item() <= 1e-4 * scale + 1e-6, (n, (a - b).abs().max().item(), scale)
+    for other in (inc, loop):
+        for n, a, b in zip(names, dense, other):
+            scale = max(a.abs().max().item(), 1e-6)
+            assert (a - b).abs().max().item() <= 1e-4 * scale + 1e-6, (n, (a - b).abs().max().item(), scale)
     # the path really ran: the projection is formed and is sparse on a constructive teacher's rollout
     xp = net._incremental_projection(obs["image"], N)
     assert xp is not None and xp.shape == (T * N, 1024)
