@@ -99,23 +99,24 @@ class MultigridNetwork(DeviceAwareModule):
             p = oy * O + ox
             order = torch.argsort(p, stable=True)                                           # group the triples by position
             counts_dev = torch.bincount(p, minlength=P)
-            counts = counts_dev.cpu().tolist()                                              # (one host sync)
+            # nonzero() lists the triples of one (t, n) contiguously: the k-th triple of a row is at distance k from the
+            # first one of its run (left insertion point of the row key, which is non-decreasing)
+            key = (tt + 1) * N + nn_
+            rank = torch.arange(M, device=image.device) - torch.searchsorted(key, key)
+            same0 = (img[0] == img[0, :1]).all()                                            # every sequence starts from one frame
+            host = torch.cat([counts_dev, rank.max().view(1) if M else counts_dev.new_zeros(1), same0.view(1).long()]).cpu().tolist()
+            counts, kmax, same0 = host[:P], host[P] + 1, bool(host[P + 1])                  # (one host sync)
             tt, nn_, oy, ox = tt[order], nn_[order], oy[order], ox[order]
             row_t, row_prev = (tt + 1) * N + nn_, tt * N + nn_
             cmax = max(counts) if counts else 0
             batched = M > 0 and cmax * P <= self.INCREMENTAL_MAX_PADDING * M
-            if batched:                                      # slot of triple i in the [P, cmax] padded layout; padding -> row TN
+            if batched:                                      # slot of triple i in the [P, cmax] padded layout
                 starts = torch.cumsum(counts_dev, 0) - counts_dev
                 p_sorted = p[order]
                 slot = p_sorted * cmax + (torch.arange(M, device=image.device) - starts[p_sorted])
                 row_of = torch.zeros((P * cmax,), dtype=torch.long, device=image.device)   # padding -> row 0 (unused grad)
                 row_of[slot] = row_t
-                # src[r, k]: slot of the k-th triple of row r.  nonzero() lists the triples of one (t, n) contiguously:
-                # k = distance to the first triple of the run (left insertion point of the key)
-                key = row_t[torch.argsort(order)]                                          # rows in nonzero() order
-                rank = torch.arange(M, device=image.device) - torch.searchsorted(key, key)  # key is non-decreasing
-                kmax = int(rank.max()) + 1                                                 # (second host sync)
-                src = torch.full((TN, kmax), -1, dtype=torch.int32, device=image.device)
+                src = torch.full((TN, kmax), -1, dtype=torch.int32, device=image.device)   # src[r, k]: slot of row r's k-th triple
                 slot_u = torch.empty_like(slot)
                 slot_u[order] = slot
                 src[key, rank] = slot_u.to(torch.int32)
@@ -126,7 +127,10 @@ class MultigridNetwork(DeviceAwareModule):
         wc, w_ih = conv.weight.view(F, -1), lstm.weight_ih_l0
         wf = w_ih[:, :F * P]
         xp = torch.zeros((TN, G), device=image.device, dtype=image.dtype)
-        xp[:N] = self.image_conv(img[0]) @ wf.t()                                            # t = 0: dense
+        if same0:                                       # the teacher's first frame is the same empty grid in every env:
+            xp[:N] = (self.image_conv(img[0, :1]) @ wf.t()).expand(N, G)                     # one row, not a [N, 21632] GEMM
+        else:
+            xp[:N] = self.image_conv(img[0]) @ wf.t()                                        # t = 0: dense
         if M:
             act = lambda rows: torch.relu(torch.addmm(conv.bias, flat[rows.unsqueeze(1), col], wc.t()))
             delta = act(row_t) - act(row_prev)                                               # [M, F] feature change per triple

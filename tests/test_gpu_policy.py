@@ -222,7 +222,7 @@ def test_incremental_teacher_projection_matches_dense_path(monkeypatch):
     assert net._incremental_eligible(obs["image"], N)
     w = torch.randn(T * N, 1, device=DEV)
 
-    def run(flag):
+    def run(flag, obs=obs):
         monkeypatch.setenv("DCD_INCREMENTAL_PROJECTION", flag)
         net.zero_grad()
         v, lp, ent, _ = net.evaluate_actions(obs, hxs, masks, actions)
@@ -238,6 +238,13 @@ def test_incremental_teacher_projection_matches_dense_path(monkeypatch):
         for n, a, b in zip(names, dense, other):
             scale = max(a.abs().max().item(), 1e-6)
             assert (a - b).abs().max().item() <= 1e-4 * scale + 1e-6, (n, (a - b).abs().max().item(), scale)
+    # the rollout starts every env from the same empty grid (projected once); with one env's first frame altered the
+    # t = 0 block goes through the dense GEMM again
+    obs2 = {k: v.clone() for k, v in obs.items()}
+    obs2["image"][1, 0, 4, 5] = 3.0
+    for n, a, b in zip(names, run("0", obs2), run("1", obs2)):
+        scale = max(a.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() <= 1e-4 * scale + 1e-6, (n, (a - b).abs().max().item(), scale)
     # the path really ran: the projection is formed and is sparse on a constructive teacher's rollout
     xp = net._incremental_projection(obs["image"], N)
     assert xp is not None and xp.shape == (T * N, 1024)
