@@ -189,7 +189,7 @@ class MaskedLSTMSequence(torch.autograd.Function):
         T, N, G = xp.shape
         H = G // 4
         xp, masks, c0 = xp.contiguous(), masks.contiguous().float(), c0.contiguous()
-        act = torch.empty_like(xp)
+        act = xp.clone()            # gates accumulate in place (beta = 1): addmm(xp[t], ..., out=act[t]) copied xp[t] per step
         cs = torch.empty((T, N, H), device=xp.device)
         out = torch.empty((T, N, H), device=xp.device)
         hm = torch.empty((T, N, H), device=xp.device)
@@ -197,7 +197,7 @@ class MaskedLSTMSequence(torch.autograd.Function):
         w_hh_t = w_hh.t()
         L, st = lib(), stream_ptr()
         for t in range(T):
-            torch.addmm(xp[t], hm[t], w_hh_t, out=act[t])
+            act[t].addmm_(hm[t], w_hh_t)
             nxt = t + 1 < T
             check(L.dcd_lstm_seq_fwd_step(ptr(act[t]), ptr(cs[t - 1] if t else c0), ptr(masks[t]), ptr(masks[t + 1]) if nxt else None,
                                           ptr(cs[t]), ptr(out[t]), ptr(hm[t + 1]) if nxt else None, C.c_int32(N), C.c_int32(H), st))
