@@ -146,6 +146,11 @@ class StudentActor:
                       st.action_log_dist[step], deterministic=deterministic)
 
 
+def incremental_act_enabled():
+    """DCD_INCREMENTAL_ACT=0: the teacher's rollout multiplies the dense 21 632-wide operand at every step."""
+    return os.environ.get("DCD_INCREMENTAL_ACT", "1") != "0"
+
+
 class GridActor:
     """Rollout-time policy step of a recurrent, grid-observing MultigridNetwork (the PAIRED teacher: 15 x 15 image,
     128 filters, time-step embedding, random_z, LSTM-256): `dcd_policy_grid_features` writes the GEMM operand row
@@ -207,6 +212,9 @@ class GridActor:
             self.w_t[:self.K - self.H].copy_(l.weight_ih_l0.t())
             self.w_t[self.K - self.H:self.K].copy_(l.weight_hh_l0.t())
             torch.add(l.bias_ih_l0, l.bias_hh_l0, out=self.bias)
+            F, G = self._dims["F"], 4 * self.H
+            P = (self._dims["V"] - 2) ** 2
+            self.wp = l.weight_ih_l0[:, :F * P].view(G, F, P).permute(2, 1, 0).contiguous()      # [P, F, 4H]: per-position blocks
         s = StudentNet()
         for name, p in zip(("conv_w", "conv_b", "embed_w", "embed_b"), self._params):
             setattr(s, name, ptr(p.detach(), torch.float32, name=name).value)
@@ -214,7 +222,94 @@ class GridActor:
             setattr(s, k, v)
         self._struct, self._w_version = s, ver
 
-    def act(self, obs, hc_in, masks, deterministic=False):
+    # ---- incremental acting: the image part of the projection is carried from step to step ------------------------
+    def begin_episode(self):
+        """Call before the first step of a teacher episode: forget the carried projection."""
+        self._xp_img, self._incremental = None, incremental_act_enabled()
+
+    def _carry_projection(self, image, prev_image):
+        """self._xp_img [B, 4H] = relu(conv(image)).flatten(1) @ W_ih[:, :F*P]^T, carried: at the first step every env
+        shows the same empty grid (one row, broadcast); afterwards a teacher action changes one or two cells, i.e.
+        <= 18 of the P conv positions — only their feature changes are multiplied (one batched GEMM over positions,
+        rows summed by dcd_gather_sum_rows), the same form PPO.update uses (MultigridNetwork._incremental_projection).
+        Returns False when this episode has to use the dense operand (first frames differ)."""
+        import torch.nn.functional as Fn
+        net, B, G = self.net, self.B, 4 * self.H
+        S, F = self._dims["V"], self._dims["F"]
+        O = S - 2
+        P = O * O
+        if prev_image is None:
+            if not bool((image == image[:1]).all()):                               # (host sync)
+                return False
+            self._xp_img = (net.image_conv(image[:1]) @ self._lstm.weight_ih_l0[:, :F * P].t()).expand(B, G).contiguous()
+            return True
+        if self._xp_img is None:
+            return False
+        dev = image.device
+        changed = (image != prev_image).any(dim=1)                                 # [B,S,S]
+        dirty = Fn.max_pool2d(changed.float().unsqueeze(1), 3, 1).squeeze(1) > 0   # [B,O,O]: conv positions that see a change
+        nn_, oy, ox = dirty.nonzero(as_tuple=True)                                 # (host sync) rows in (env, position) order
+        M = nn_.numel()
+        if M == 0:
+            return True
+        p = oy * O + ox
+        counts = torch.bincount(p, minlength=P)
+        rank = torch.arange(M, device=dev) - torch.searchsorted(nn_, nn_)          # k-th dirty position of its env
+        cmax, kmax = torch.stack([counts.max(), rank.max() + 1]).tolist()          # (host sync)
+        order = torch.argsort(p, stable=True)
+        p_s, n_s = p[order], nn_[order]
+        slot = p_s * cmax + (torch.arange(M, device=dev) - (torch.cumsum(counts, 0) - counts)[p_s])
+        src = torch.full((B, kmax), -1, dtype=torch.int32, device=dev)
+        slot_u = torch.empty_like(slot)
+        slot_u[order] = slot
+        src[nn_, rank] = slot_u.to(torch.int32)
+        k = torch.arange(3, device=dev)
+        offs = (torch.arange(3, device=dev).view(3, 1, 1) * S * S + k.view(1, 3, 1) * S + k.view(1, 1, 3)).reshape(-1)
+        col = (oy[order] * S + ox[order]).unsqueeze(1) + offs.unsqueeze(0)         # [M, 27]: the 3x3x3 window of each pair
+        conv = net.image_conv[0]
+        wc = conv.weight.view(F, -1).t()
+        rows = n_s.unsqueeze(1)
+        feat = lambda im: torch.relu(torch.addmm(conv.bias, im.reshape(B, -1)[rows, col], wc))
+        dpad = torch.zeros((P * cmax, F), device=dev).index_copy_(0, slot, feat(image) - feat(prev_image))
+        y = torch.bmm(dpad.view(P, cmax, F), self.wp).view(P * cmax, G)
+        check(lib().dcd_gather_sum_rows(ptr(y, torch.float32), ptr(src, torch.int32), ptr(self._xp_img, torch.float32), C.c_int32(B),
+                                        C.c_int32(kmax), C.c_int32(G), stream_ptr()))
+        return True
+
+    def act(self, obs, hc_in, masks, deterministic=False, prev_image=None, first=False):
+        """`first` / `prev_image` (the previous step's image of the same episode) enable the carried projection
+        (`begin_episode` must have been called); without them every step multiplies the dense operand."""
+        if (first or prev_image is not None) and getattr(self, "_incremental", False) and not torch.cuda.is_current_stream_capturing():
+            self._incremental = self._carry_projection(obs["image"], None if first else prev_image)
+            if self._incremental:
+                return self._act_carried(obs, hc_in, masks, deterministic)
+        return self._act_dense(obs, hc_in, masks, deterministic)
+
+    def _act_carried(self, obs, hc_in, masks, deterministic):
+        from models.common import one_hot
+        net, H = self.net, self.H
+        scalar = obs.get("direction")
+        if scalar is None:
+            scalar = obs.get("time_step")
+        rest = [net.scalar_embed(one_hot(net.scalar_dim, scalar))]
+        if self.Z:
+            rest.append(obs["random_z"])
+        rest.append(hc_in[:, :H] * masks)
+        FP = self.K - self.H - self.Z - self._dims["E"]
+        self.gates = torch.addmm(self._xp_img, torch.cat(rest, dim=1), self.w_t[FP:self.K]) + self.bias
+        return self._finish(hc_in, masks, deterministic)
+
+    def _finish(self, hc_in, masks, deterministic):
+        H = self.H
+        i, f, g, o = self.gates.split(H, dim=1)
+        c = torch.sigmoid(f) * (hc_in[:, H:] * masks) + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        dist = self.net.actor(h)
+        value = self.net.critic(h)
+        action = dist.mode() if deterministic else dist.sample()
+        return value, action, dist.logits, (h, c)
+
+    def _act_dense(self, obs, hc_in, masks, deterministic=False):
         """`net.act(obs, (h, c), masks)` (multigrid_models.py:141-167): value [B,1], action [B,1], normalised logits
         [B,A], (h', c').  obs: dict with image / time_step (or direction) / random_z; hc_in: [B, 2H] = h | c."""
         B, H, s = self.B, self.H, self._struct
@@ -227,11 +322,7 @@ class GridActor:
             ptr(z, torch.float32, B * self.Z, "random_z") if z is not None else None, C.c_int32(self.Z),
             ptr(hc_in, torch.float32, B * 2 * H, "hc_in"), ptr(masks, torch.float32, B, "masks"), ptr(self.x), C.c_int32(self.KP),
             C.c_int32(B), stream_ptr()))
+        if self.gates.data_ptr() == 0 or self.gates.shape != (B, 4 * H):
+            self.gates = torch.empty((B, 4 * H), device=self.x.device)
         torch.addmm(self.bias, self.x, self.w_t, out=self.gates)
-        i, f, g, o = self.gates.split(H, dim=1)
-        c = torch.sigmoid(f) * (hc_in[:, H:] * masks) + torch.sigmoid(i) * torch.tanh(g)
-        h = torch.sigmoid(o) * torch.tanh(c)
-        dist = self.net.actor(h)
-        value = self.net.critic(h)
-        action = dist.mode() if deterministic else dist.sample()
-        return value, action, dist.logits, (h, c)
+        return self._finish(hc_in, masks, deterministic)

@@ -346,10 +346,14 @@ class AdversarialRunner:
         grid_actor = self._grid_actor(agent) if self.is_discrete_adversary_env_actions else None
         if grid_actor is not None:
             grid_actor.refresh()
+            if t0 == 0:
+                grid_actor.begin_episode()
         for step in range(t0, t1):
             with torch.no_grad():
                 if grid_actor is not None:
-                    value, action, log_dist, hxs = grid_actor.act(st.get_obs(step), st.recurrent_hidden_states[step], st.masks[step])
+                    value, action, log_dist, hxs = grid_actor.act(
+                        st.get_obs(step), st.recurrent_hidden_states[step], st.masks[step], first=step == 0,
+                        prev_image=st.obs["image"][step - 1] if step else None)
                 else:
                     value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step),
                                                              st.masks[step])

@@ -304,3 +304,49 @@ def test_grid_actor_matches_teacher_module():
         assert torch.equal(a0[clear], a1[clear])
     assert st.actions.min() >= 0 and st.actions.max() < 169 and torch.isfinite(st.value_preds).all()
     venv.close()
+
+
+def test_grid_actor_carried_projection_matches_dense_operand(monkeypatch):
+    """Teacher acting with the image projection carried from step to step (first frame projected once, then only the
+    conv positions that see a changed cell) vs the dense 21 948-wide operand at every step, over all 27 steps of a real
+    teacher episode: value, logits and (h', c') within 2e-5 of each tensor's scale at every step (the carried sum adds
+    <= 18 products per step in fp32), and the carried path really was taken."""
+    from dcd_hip.policy import GridActor
+    from tests.test_gpu_runner import build, make_args
+    args = make_args(ued_algo="paired", num_processes=40)
+    runner, venv = build(args)
+    teacher = runner.agents["adversary_env"]
+    net, st = teacher.algo.actor_critic, teacher.storage
+    runner._teacher_rollout(teacher, runner.adversary_env_rollout_steps)
+    ga, gd = GridActor(net, 40), GridActor(net, 40)
+    ga.begin_episode()
+    assert ga._incremental
+    worst = 0.0
+    for step in range(runner.adversary_env_rollout_steps):
+        obs, hc, masks = st.get_obs(step), st.recurrent_hidden_states[step], st.masks[step]
+        with torch.no_grad():
+            v0, a0, l0, (h0, c0) = gd.act(obs, hc, masks, deterministic=True)
+            v1, a1, l1, (h1, c1) = ga.act(obs, hc, masks, deterministic=True, first=step == 0,
+                                          prev_image=st.obs["image"][step - 1] if step else None)
+        assert ga._incremental and ga._xp_img is not None, step
+        for n, a, b in (("value", v0, v1), ("logits", l0, l1), ("h", h0, h1), ("c", c0, c1)):
+            err = (a - b).abs().max().item() / max(a.abs().max().item(), 1.0)
+            worst = max(worst, err)
+            assert err <= 2e-5, (step, n, err)
+        top2 = l0.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert torch.equal(a0[clear], a1[clear])
+    # first frames that differ between envs: the episode falls back to the dense operand
+    gf = GridActor(net, 40)
+    gf.begin_episode()
+    obs = {k: v.clone() for k, v in st.get_obs(0).items()}
+    obs["image"][3, 0, 5, 5] = 2.0
+    with torch.no_grad():
+        gf.act(obs, st.recurrent_hidden_states[0], st.masks[0], deterministic=True, first=True)
+    assert not gf._incremental
+    # DCD_INCREMENTAL_ACT=0: never carried
+    monkeypatch.setenv("DCD_INCREMENTAL_ACT", "0")
+    g0 = GridActor(net, 40)
+    g0.begin_episode()
+    assert not g0._incremental
+    venv.close()
