@@ -283,6 +283,7 @@ class GridActor:
             self._incremental = self._carry_projection(obs["image"], None if first else prev_image)
             if self._incremental:
                 return self._act_carried(obs, hc_in, masks, deterministic)
+        self._incremental = False                            # a step that was not carried breaks the chain for this episode
         return self._act_dense(obs, hc_in, masks, deterministic)
 
     def _act_carried(self, obs, hc_in, masks, deterministic):
