@@ -183,6 +183,7 @@ int SFX(dcd_big_create)(const DcdMgConfig* cfg, int device, void** out) {
   p.random_z_dim = cfg->random_z_dim; p.n_editor_actions = NEDIT[cfg->editor_actions];
   p.fixed_environment = cfg->fixed_environment; p.goal_noise = cfg->goal_noise; p.engine_seed = cfg->engine_seed;
   p.see_through_walls = cfg->see_through_walls != 0;
+  init_reward_division(p);
   const size_t B = (size_t)p.B;
   const uint32_t init[2] = {0u, 0x7fffffffu};
   hipError_t e = hipMalloc(&h->rec, B * REC_BYTES);

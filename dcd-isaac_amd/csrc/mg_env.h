@@ -84,6 +84,8 @@ struct Params {
   float goal_noise;
   uint32_t engine_seed;
   int32_t see_through_walls;   // 0: gen_obs_grid masks the view with Grid.process_vis (multigrid.py:1000-1002)
+  int32_t fast_div;            // step_count / max_steps may be formed from inv_max_steps (init_reward_division)
+  double inv_max_steps;
 };
 
 // ---------------------------------------------------------------- Philox4x32-10 (Salmon et al. SC'11)
@@ -154,6 +156,7 @@ struct Env {
   int doff0, doff1;    // scalars, not an array: a dynamically indexed member would pin the whole Env to scratch
   int nd;
   bool full_dirty;
+  bool ctr_dirty;     // the draw counter bytes (side column rows 8..11) changed
   // dynamic state (bytes 240..255 of the record)
   int ax, ay, adir, carrying, done;
   int step_count, elapsed, ep_len;
@@ -191,12 +194,24 @@ struct Env {
     q[0] = w[0]; q[1] = w[1]; q[2] = w[2]; q[3] = w[3];
   }
   // rng draw counter lives in SB8..11
-  DCD_HDM uint32_t ctr() { return sb(8) | (sb(9) << 8) | (sb(10) << 16) | ((uint32_t)sb(11) << 24); }
-  DCD_HDM void set_ctr(uint32_t v) { sb(8) = (uint8_t)v; sb(9) = (uint8_t)(v >> 8); sb(10) = (uint8_t)(v >> 16); sb(11) = (uint8_t)(v >> 24); full_dirty = true; }
+  DCD_HDM uint32_t ctr_bytes() { return sb(8) | (sb(9) << 8) | (sb(10) << 16) | ((uint32_t)sb(11) << 24); }
+  DCD_HDM uint32_t ctr() { return cached ? c_ctr : ctr_bytes(); }
+  DCD_HDM void set_ctr(uint32_t v) { sb(8) = (uint8_t)v; sb(9) = (uint8_t)(v >> 8); sb(10) = (uint8_t)(v >> 16); sb(11) = (uint8_t)(v >> 24); c_ctr = v; ctr_dirty = true; }
+  // Start pose (SB0..2) and draw counter as registers.  The step kernel reads them ONCE next to the dynamic state
+  // (cache_side): the end of an episode needs all seven, and as dependent single-byte LDS reads inside the divergent
+  // goal path they cost ~1000 cycles in the slowest workgroup of a launch.  Level-building code writes SB0..2 and never
+  // sets `cached`; the one in-step writer (env_reset_random) drops the cache first.
+  int c_sx, c_sy, c_sd; uint32_t c_ctr; bool cached;
+  int pending_done;     // agent_is_done left placements to finish_agent_done (1: carried object, 2: + observable respawn)
+  DCD_HDM void cache_side() { c_sx = sb(0); c_sy = sb(1); c_sd = sb(2); c_ctr = ctr_bytes(); cached = true; }
+  DCD_HDM int start_x() { return cached ? c_sx : (int)sb(0); }
+  DCD_HDM int start_y() { return cached ? c_sy : (int)sb(1); }
+  DCD_HDM int start_dir() { return cached ? c_sd : (int)sb(2); }
 };
 
 DCD_HD Env make_env(DCD_REC uint8_t* rec, uint32_t seed) {
-  Env e; e.r = rec; e.seed = seed; e.err = 0; e.nd = 0; e.full_dirty = false; e.doff0 = e.doff1 = 0;
+  Env e; e.r = rec; e.seed = seed; e.err = 0; e.nd = 0; e.full_dirty = false; e.ctr_dirty = false; e.doff0 = e.doff1 = 0;
+  e.cached = false; e.c_sx = e.c_sy = e.c_sd = 0; e.c_ctr = 0; e.pending_done = 0;
   e.load_dyn();
   return e;
 }
@@ -343,15 +358,16 @@ DCD_HD bool place_one_agent(Env& e, const Params& p, bool rand_dir, int* px, int
   return true;
 }
 DCD_HD void reset_agent_status(Env& e) {                                  // adversarial.py:231-236
-  e.ax = NOPOS; e.adir = e.sb(2); e.done = 0; e.carrying = C_NONE;
+  e.ax = NOPOS; e.adir = e.start_dir(); e.done = 0; e.carrying = C_NONE;
 }
 // AdversarialEnv.reset_agent (adversarial.py:238-269); TimeLimit counter is the caller's job
 DCD_HD void reset_agent(Env& e) {
   if (e.has_pos()) e.set_cell(e.ax, e.ay, C_NONE);
   reset_agent_status(e);
   e.step_count = 0;                                                      // step_count
-  if (e.sb(0) == NOPOS) { e.err |= DCD_ERR_NO_START_POS; return; }
-  place_agent_at_pos(e, e.sb(0), e.sb(1), false);
+  const int sx = e.start_x();
+  if (sx == NOPOS) { e.err |= DCD_ERR_NO_START_POS; return; }
+  place_agent_at_pos(e, sx, e.start_y(), false);
 }
 
 // compute_metrics (adversarial.py:190-192,407-447): wall count + BFS on the interior graph with
@@ -519,6 +535,7 @@ DCD_HD bool board_take(Env& e, const Params& p, FreeBoard& fb, int* px, int* py)
 
 // reset_random (adversarial.py:541-581)
 DCD_HD void env_reset_random(Env& e, const Params& p, Metrics& m) {
+  e.cached = false;                                         // writes the start pose below
   if (p.fixed_environment) e.set_ctr(0);
   e.step_count = 0; e.sb(6) = 0;
   reset_agent_status(e);
@@ -630,13 +647,47 @@ DCD_HD void env_mutate_level(Env& e, const Params& p, Metrics& m, int num_edits)
 // info['truncated_obs'] when the time limit fires on the same step.  When it is
 // not (need_pos == false) the draw is still consumed — the counter stays in lock-step with the
 // oracle — but the 225-cell scan is skipped and the agent is left unplaced.
+// The two placements (a carried object dropped on a random free cell, the observable respawn) are large and almost
+// never run: they are only REQUESTED here (pending_done) and executed by finish_agent_done at the end of
+// step_one_agent, so that the path every reached goal takes stays a few instructions inside the hot code — with
+// the placements inlined in the middle of it, skipping them cost two instruction-cache misses (~800 cycles) in the
+// slowest workgroup of most launches.  Same operations in the same order (the draws keep their counters).
 DCD_HD void agent_is_done(Env& e, const Params& p, bool need_pos) {
   e.set_cell(e.ax, e.ay, C_NONE);
   e.done = 1;
+  if (DCD_RARE(e.carrying != C_NONE || need_pos)) { e.pending_done = need_pos ? 2 : 1; return; }
+  e.ax = NOPOS; e.adir = 0; e.set_ctr(e.ctr() + 1);
+}
+DCD_HD void finish_agent_done(Env& e, const Params& p) {
   int px, py;
   if (e.carrying != C_NONE) { place_uniform(e, p, (uint8_t)e.carrying, &px, &py); e.carrying = C_NONE; }
-  if (need_pos) place_one_agent(e, p, true, &px, &py);
+  if (e.pending_done == 2) place_one_agent(e, p, true, &px, &py);
   else { e.ax = NOPOS; e.adir = 0; e.set_ctr(e.ctr() + 1); }
+  e.pending_done = 0;
+}
+
+// MiniGridEnv._reward: 1 - 0.9 * (step_count / max_steps) in fp64.  The quotient by the launch-constant max_steps is
+// formed from its reciprocal with one FMA correction (q0 = n*r; q = fma(fma(-q0, d, n), r, q0)); the engine checks at
+// creation that this equals the IEEE quotient for EVERY step count 0..max_steps (Params::fast_div), otherwise the
+// division itself runs.  The fp64 division sat in the divergent goal path of the slowest workgroup of a launch.
+DCD_HD double step_quotient_fast(double n, double d, double r) {
+  const double q0 = n * r;
+  return __builtin_fma(__builtin_fma(-q0, d, n), r, q0);
+}
+DCD_HD double goal_reward(const Params& p, int step_count) {
+  const double n = (double)step_count, d = (double)p.max_steps;
+  const double q = p.fast_div ? step_quotient_fast(n, d, p.inv_max_steps) : n / d;
+  return 1.0 - 0.9 * q;
+}
+
+// host side, at engine creation: enable the reciprocal form only if it reproduces the IEEE quotient for every step count
+inline void init_reward_division(Params& p) {
+  p.fast_div = 0; p.inv_max_steps = 0.0;
+  if (p.max_steps <= 0) return;
+  const double d = (double)p.max_steps, r = 1.0 / d;
+  for (int n = 0; n <= p.max_steps; ++n)
+    if (step_quotient_fast((double)n, d, r) != (double)n / d) return;
+  p.inv_max_steps = r; p.fast_div = 1;
 }
 
 // step_one_agent (multigrid.py:866-941); returns the fp64 reward rounded to fp32 (obs_wrappers.py:179)
@@ -654,11 +705,9 @@ DCD_HD double step_one_agent(Env& e, const Params& p, int action, int step_count
     e.set_cell(e.ax, e.ay, (uint8_t)(C_AGENT0 + e.adir));
   } else if (action == DCD_ACT_FORWARD) {
     if (DCD_RARE(!ok)) {
-    } else if (DCD_RARE(fwd == C_GOAL)) {
-      agent_is_done(e, p, need_respawn_pos);
-      reward = 1.0 - 0.9 * ((double)step_count / (double)p.max_steps);     // MiniGridEnv._reward
-    } else if (DCD_RARE(fwd == C_LAVA)) {
-      agent_is_done(e, p, need_respawn_pos);
+    } else if (fwd == C_GOAL || fwd == C_LAVA) {       // NOT hinted rare: some workgroup of nearly every launch takes it,
+      agent_is_done(e, p, need_respawn_pos);           // and laid out of line it cost ~1000 cycles of instruction fetch
+      if (fwd == C_GOAL) reward = goal_reward(p, step_count);               // MiniGridEnv._reward
     } else if (fwd == C_NONE || can_overlap(fwd)) {                         // move_agent :840-853
       e.set_cell(e.ax, e.ay, C_NONE);
       e.ax = fx; e.ay = fy;
@@ -679,6 +728,7 @@ DCD_HD double step_one_agent(Env& e, const Params& p, int action, int step_count
       e.set_cell(fx, fy, C_NONE);                                            // Box.toggle: contents (None)
     }
   }
+  if (DCD_RARE(e.pending_done)) finish_agent_done(e, p);
   return reward;
 }
 

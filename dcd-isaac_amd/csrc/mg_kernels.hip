@@ -207,7 +207,7 @@ struct StepArgs {
 // staging and the fused render/emit.  Small batches use EPB=16 so that B=4096 still spreads over all
 // 256 CUs; large batches use EPB=64 (every lane of the logic wave busy).
 // per-env results handed from the logic lane to the duty waves through LDS
-struct StepRes { float reward, ep_ret; int ep_len; uint32_t flags; uint32_t doff; };   // flags: done | info<<8 | full_dirty<<16 | nd<<20
+struct StepRes { float reward, ep_ret; int ep_len; uint32_t flags; uint32_t doff; };   // flags: done | info<<8 | full_dirty<<16 | ctr_dirty<<17 | nd<<20
 
 // Workgroup = NT worker threads + 2 duty waves.  Thread roles:
 //   wave 0, lanes [0,EPB)      per-env logic (one env per lane), result -> LDS
@@ -254,6 +254,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
     const bool live = tid < n;
     const int step_flags = RR ? a.flags : (a.flags & ~DCD_STEP_RESET_RANDOM);
     Env e = make_env(as_lds(lds + (live ? tid : 0) * LP), seed);
+    e.cache_side();
     Metrics m = {0, 0, 0, 0}; bool mdirty = false;
     if (RR && live && (step_flags & DCD_STEP_RESET_RANDOM)) m = a.met[env];
     StepResult r = {};
@@ -301,7 +302,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
       e.store_dyn();                                 // LDS copy feeds the render and the write-back wave
       StepRes sr;
       sr.reward = r.reward; sr.ep_ret = r.ep_ret; sr.ep_len = r.ep_len;
-      sr.flags = (uint32_t)r.done | ((uint32_t)r.info << 8) | ((uint32_t)(e.full_dirty ? 1 : 0) << 16) | ((uint32_t)min(e.nd, 2) << 20);
+      sr.flags = (uint32_t)r.done | ((uint32_t)r.info << 8) | ((uint32_t)(e.full_dirty ? 1 : 0) << 16) | ((uint32_t)(e.ctr_dirty ? 1 : 0) << 17) | ((uint32_t)min(e.nd, 2) << 20);
       sr.doff = (uint32_t)e.doff0 | ((uint32_t)e.doff1 << 16);
       res[tid] = sr;
       if (RR && DCD_RARE(mdirty)) a.met[env] = m;
@@ -349,6 +350,10 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
         const uint8_t c0 = src[o0], c1 = src[o1];
         if (nd > 0) g[o0] = c0;
         if (nd > 1) g[o1] = c1;
+        if ((sr.flags >> 17) & 1) {                      // the draw counter moved (a goal was reached): side bytes of rows 8..11
+#pragma unroll
+          for (int k = 8; k < 12; ++k) g[k * ROW + SIDE] = src[k * ROW + SIDE];
+        }
         *reinterpret_cast<uint4*>(g + DYN) = dyn;
       }
     }
@@ -652,6 +657,7 @@ int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out) {
   p.random_z_dim = cfg->random_z_dim; p.n_editor_actions = NEDIT[cfg->editor_actions];
   p.fixed_environment = cfg->fixed_environment; p.goal_noise = cfg->goal_noise; p.engine_seed = cfg->engine_seed;
   p.see_through_walls = cfg->see_through_walls != 0;
+  init_reward_division(p);
   const size_t B = (size_t)p.B;
   const uint32_t init[2] = {0u, 0x7fffffffu};
   hipError_t e = hipMalloc(&h->rec, B * REC_BYTES);

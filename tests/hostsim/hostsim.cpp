@@ -73,6 +73,7 @@ SimMg* sim_mg_create(const DcdMgConfig* cfg) {
   p.choose_goal_last = cfg->choose_goal_last; p.random_z_dim = cfg->random_z_dim; p.n_editor_actions = NEDIT[cfg->editor_actions];
   p.fixed_environment = cfg->fixed_environment; p.goal_noise = cfg->goal_noise; p.engine_seed = cfg->engine_seed;
   p.see_through_walls = cfg->see_through_walls != 0;
+  init_reward_division(p);
   h->rec.assign((size_t)p.B * REC_BYTES, 0);
   h->seed.resize(p.B); h->met.resize(p.B);
   for (int i = 0; i < p.B; ++i) {

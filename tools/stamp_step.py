@@ -26,12 +26,16 @@ names = ["init_luts", "stage_in", "logic", "dyn store+writeback", "render_emit",
 import numpy as np
 acc = []
 spans = []
+events = []
 for t in range(300):
     a = dcd_hip.engine.random_actions(B, 0, 3, t, 7, "cuda")
     eng.step(a, 0, outb)
     torch.cuda.synchronize()
     s = st.cpu().numpy()
     acc.append(np.diff(s[:, :7], axis=1))
+    dn = outb["done"].view(nblk, -1).any(1).cpu().numpy() if B % nblk == 0 else None
+    rw = (outb["reward"].view(nblk, -1) > 0).any(1).cpu().numpy() if B % nblk == 0 else None
+    events.append((dn, rw))
     span = (s[:, 1:7].max() - s[:, 0].min())
     spans.append(span)
 spans = np.array(spans)
@@ -50,5 +54,14 @@ for i, n in enumerate(names):
 wl = tot.max(1).argmax(); wb = tot[wl].argmax()
 print("worst launch: step", 5 + wl, "block", wb, "phases", dict(zip(names, acc[wl, wb].tolist())), "median phases of that launch", dict(zip(names, np.median(acc[wl], axis=0).tolist())))
 print("percentiles of per-block total (50/90/99/100):", np.percentile(tot, [50, 90, 99, 100]))
+if events[0][0] is not None:
+    ev = events[5:]
+    logic = acc[:, :, 2]
+    dn = np.stack([e[0] for e in ev]); rw = np.stack([e[1] for e in ev])
+    print("logic cycles, blocks with no episode end: median", np.median(logic[~dn]), "p99", np.percentile(logic[~dn], 99), "max", logic[~dn].max())
+    print("logic cycles, blocks with a goal reached:", "median", np.median(logic[rw]) if rw.any() else None, "n", int(rw.sum()))
+    print("logic cycles, blocks with an episode end w/o goal:", "median", np.median(logic[dn & ~rw]) if (dn & ~rw).any() else None, "n", int((dn & ~rw).sum()))
+    slow = [(dn[l, worst[l]], rw[l, worst[l]]) for l in range(len(worst))]
+    print("slowest block of a launch: has episode end in", np.mean([a for a, _ in slow]), "of launches, a goal in", np.mean([b for _, b in slow]))
 spans = []
 
