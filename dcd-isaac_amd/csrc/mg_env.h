@@ -112,7 +112,7 @@ DCD_HD bool can_overlap(uint8_t c) {   // gym_minigrid WorldObj.can_overlap: Goa
 }
 DCD_HD bool can_pickup(uint8_t c) { return c >= C_KEY0 && c < C_GOAL; }   // Key, Ball, Box
 // WorldObj.encode / Agent.encode (multigrid.py:138-140); None -> (1,0,0) (Grid.encode)
-DCD_HD uint32_t enc3(uint8_t c) {     // type | colour<<8 | state<<16
+DCD_HD constexpr uint32_t enc3(uint8_t c) {     // type | colour<<8 | state<<16
   if (c == C_NONE) return DCD_OBJ_EMPTY;
   if (c < C_FLOOR0) return DCD_OBJ_WALL | ((uint32_t)(c - C_WALL0) << 8);
   if (c < C_KEY0) return DCD_OBJ_FLOOR | ((uint32_t)(c - C_FLOOR0) << 8);
@@ -125,6 +125,30 @@ DCD_HD uint32_t enc3(uint8_t c) {     // type | colour<<8 | state<<16
   uint32_t d = c - C_DOOR0;
   return DCD_OBJ_DOOR | ((d / 3) << 8) | ((d % 3) << 16);
 }
+// The same map without branches (the step kernel builds its code -> encoding LUT with it at the start of every launch,
+// one code per lane of the logic wave: as eleven nested range tests that was ~70 instructions of exec-mask juggling on
+// the critical path).  Families of six colours: k = c - 1, family k / 6 = (k * 43) >> 8 for k < 30, types 2,3,5,6,7
+// packed in 0x76532; doors: d / 3 = (d * 171) >> 9 for d < 18.  Checked against enc3 for every code at compile time.
+DCD_HD constexpr uint32_t enc3_flat(uint32_t c) {
+  const uint32_t k = c - 1u;
+  const uint32_t g = ((k * 43u) >> 8) & 7u;
+  const uint32_t fam = ((0x76532u >> (4u * g)) & 15u) | ((k - 6u * g) << 8);
+  const uint32_t d = c - (uint32_t)C_DOOR0;
+  const uint32_t dc = ((d * 171u) >> 9) & 7u;
+  const uint32_t door = (uint32_t)DCD_OBJ_DOOR | (dc << 8) | ((d - 3u * dc) << 16);
+  uint32_t r = fam;
+  r = c == (uint32_t)C_NONE ? (uint32_t)DCD_OBJ_EMPTY : r;
+  r = c == (uint32_t)C_GOAL ? ((uint32_t)DCD_OBJ_GOAL | (1u << 8)) : r;
+  r = c == (uint32_t)C_LAVA ? (uint32_t)DCD_OBJ_LAVA : r;
+  r = (c >= (uint32_t)C_AGENT0 && c < (uint32_t)C_DOOR0) ? ((uint32_t)DCD_OBJ_AGENT | ((c - (uint32_t)C_AGENT0) << 16)) : r;
+  r = c >= (uint32_t)C_DOOR0 ? door : r;
+  return r;
+}
+constexpr bool enc3_flat_matches() {
+  for (uint32_t c = 0; c < (uint32_t)C_END; ++c) if (enc3_flat(c) != enc3((uint8_t)c)) return false;
+  return true;
+}
+static_assert(enc3_flat_matches(), "enc3_flat must equal enc3 on every packed code");
 // WorldObj.decode (multigrid.py:72-107); returns false on bytes the reference raises on
 DCD_HD bool dec3(uint8_t t, uint8_t col, uint8_t s, uint8_t* code) {
   *code = C_NONE;

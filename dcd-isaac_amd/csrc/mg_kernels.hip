@@ -55,7 +55,7 @@ __device__ __forceinline__ float div10f(uint32_t k) {
 }
 __device__ __forceinline__ void init_luts(Luts& l, int tid) {
   if (tid < 64) {
-    const uint32_t t = tid < C_END ? enc3((uint8_t)tid) : 0u;
+    const uint32_t t = tid < C_END ? enc3_flat((uint32_t)tid) : 0u;
     l.enc[tid] = t;
     l.f[0][tid] = div10f(t & 15); l.f[1][tid] = div10f((t >> 8) & 15); l.f[2][tid] = div10f((t >> 16) & 15);
     if (tid < 16) l.div10[tid] = div10f((uint32_t)tid);
