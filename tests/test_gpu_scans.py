@@ -142,7 +142,7 @@ def test_episode_scores_full_size_match_oracle(strategy):
         assert np.array_equal(bits(mean.cpu().numpy()), bits(rm)) and np.array_equal(bits(mx.cpu().numpy()), bits(rx))
 
 
-@pytest.mark.parametrize("T,B", [(37, 32), (256, 96), (300, 64), (513, 160), (40, 77)])
+@pytest.mark.parametrize("T,B", [(1, 32), (2, 64), (37, 32), (256, 96), (300, 64), (513, 160), (40, 77)])
 @pytest.mark.parametrize("strategy", [1, 6, 8])
 def test_episode_scores_staged_path_shapes(strategy, T, B):
     """The LDS-staged scoring path (B a multiple of 32) over one, two and three time tiles, partial tiles, blocks that
