@@ -156,7 +156,7 @@ __device__ __forceinline__ void log_softmax(const float* __restrict__ x, int A, 
 struct ScoreArgs {
   const float *ret, *val, *rew, *msk, *cliff, *logits;
   const int* seeds;
-  int T, B, A, strategy; float g;
+  int T, B, A, strategy; float g, max_entropy;
   DcdEpisodeRec* recs; int max_recs; const int* offsets;
 };
 
@@ -168,6 +168,33 @@ struct SegAcc {
   double acc, rs; float mx, mn; float r0, v0; int start; int seed;
   __device__ __forceinline__ void reset(int s) { acc = 0.0; rs = 0.0; mx = -INFINITY; mn = INFINITY; r0 = 0.f; v0 = 0.f; start = s; }
 };
+
+// policy_entropy on the episode lengths where the reference's expression is defined (level_sampler.py:283):
+// `-exp(l) * l.sum(-1) / max_entropy` broadcasts the [L,A] probabilities against the [L] row sums, which numpy/torch only
+// accept for L == 1 (every entry times the one row sum) and L == A (entry (i,j) times the sum of row j); mean and max
+// then run over all L*A entries.  Those two lengths reproduce the reference; every other length (where the reference
+// raises) scores the per-step entropy it evidently meant, accumulated by the caller.  Rare: re-reads the L rows.
+__device__ __noinline__ void entropy_reference_lengths_strided(const float* __restrict__ logits, size_t row_stride, int A, int L,
+                                                               float max_entropy, float* mean_out, float* max_out) {
+  float S[16], ls[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    S[j] = 0.f;
+    if (j < L) { log_softmax(logits + (size_t)j * row_stride, A, ls); float t = 0.f; for (int q = 0; q < A; ++q) t += ls[q]; S[j] = t; }
+  }
+  double acc = 0.0; float mx = -INFINITY;
+  for (int i = 0; i < L; ++i) {
+    log_softmax(logits + (size_t)i * row_stride, A, ls);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < A) {
+        const float v = ((-expf(ls[j])) * (L == 1 ? S[0] : S[j])) / max_entropy;
+        acc += (double)v; mx = v > mx ? v : mx;
+      }
+    }
+  }
+  *mean_out = (float)(acc / (double)(L * A)); *max_out = mx;
+}
 
 template <int ST, bool HAVE_SEED = false>
 __device__ __forceinline__ void flush_segment(const ScoreArgs& a, int b, SegAcc& sg, int end, int flags, int& k) {
@@ -183,6 +210,10 @@ __device__ __forceinline__ void flush_segment(const ScoreArgs& a, int b, SegAcc&
       else { r.mean_score = sg.r0 - sg.v0; r.max_score = r.mean_score; }                  // signed (:433)
     } else if (st == DCD_SCORE_MIN_MARGIN) {                                              // 1 - mean, 1 - min (:302-303)
       r.mean_score = (float)(1.0 - (double)(float)(sg.acc / (double)L)); r.max_score = (float)(1.0 - (double)sg.mn);
+    } else if (st == DCD_SCORE_POLICY_ENTROPY && (L == 1 || L == a.A)) {
+      // rows of one env are B*A floats apart: gather the episode's rows through a strided view
+      entropy_reference_lengths_strided(a.logits + ((size_t)sg.start * a.B + b) * a.A, (size_t)a.B * a.A, a.A, L,
+                                        a.max_entropy, &r.mean_score, &r.max_score);
     } else { r.mean_score = (float)(sg.acc / (double)L); r.max_score = sg.mx; }
     a.recs[k] = r;
   }
@@ -198,7 +229,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) seg_score_kernel(ScoreArgs a) {
   constexpr int st = ST;
   constexpr bool use_ret = st <= DCD_SCORE_SIGNED_VALUE_LOSS, use_logits = st == DCD_SCORE_POLICY_ENTROPY || st == DCD_SCORE_LEAST_CONFIDENCE || st == DCD_SCORE_MIN_MARGIN;
   constexpr bool use_val = use_ret || st == DCD_SCORE_ONE_STEP_TD;
-  const float max_entropy = (float)log((double)(A > 0 ? A : 1));
+  const float max_entropy = a.max_entropy;
   int k = a.offsets[b];
   SegAcc sg; sg.reset(0);
   float vnext = use_val ? a.val[b] : 0.f;                  // v[t] carried across chunks (TD needs v[t+1])
@@ -543,7 +574,7 @@ int dcd_episode_scores(const float* returns, const float* value_preds, const flo
     int* block_sums = offsets;
     ScoreArgs a;
     a.ret = returns; a.val = value_preds; a.rew = rewards; a.msk = masks; a.cliff = cliffhanger_masks; a.logits = nullptr;
-    a.seeds = level_seeds; a.T = T; a.B = B; a.A = A; a.strategy = strategy; a.g = (float)gamma; a.recs = recs; a.max_recs = max_recs;
+    a.seeds = level_seeds; a.T = T; a.B = B; a.A = A; a.strategy = strategy; a.g = (float)gamma; a.max_entropy = 1.f; a.recs = recs; a.max_recs = max_recs;
     a.offsets = nullptr;
     hipLaunchKernelGGL(seg_count_par_kernel, dim3((B + 63) / 64), dim3(256), 0, s, masks, T, B, counts, block_sums);
     switch (strategy) {
@@ -559,6 +590,7 @@ int dcd_episode_scores(const float* returns, const float* value_preds, const flo
   ScoreArgs a;
   a.ret = returns; a.val = value_preds; a.rew = rewards; a.msk = masks; a.cliff = cliffhanger_masks; a.logits = action_log_dist;
   a.seeds = level_seeds; a.T = T; a.B = B; a.A = A; a.strategy = strategy; a.g = (float)gamma; a.recs = recs; a.max_recs = max_recs;
+  a.max_entropy = A > 1 ? (float)(-(1.0 / A) * log(1.0 / A) * A) : 1.f;       // level_sampler.py:281, evaluated in fp64 like numpy
   a.offsets = offsets;
   switch (strategy) {
 #define DCD_SCORE_CASE(ST) case ST: hipLaunchKernelGGL(seg_score_kernel<ST>, dim3(nblk(B)), dim3(SCAN_BLOCK), 0, s, a); break;

@@ -239,7 +239,12 @@ enum {
   DCD_SCORE_VALUE_L1 = 0,            /* :318-327 */
   DCD_SCORE_POSITIVE_VALUE_LOSS = 1, /* :340-349 */
   DCD_SCORE_SIGNED_VALUE_LOSS = 2,   /* :329-338  (== gae :307-316) */
-  DCD_SCORE_POLICY_ENTROPY = 3,      /* :278-287 (with its broadcasting quirk, A.3-10) */
+  DCD_SCORE_POLICY_ENTROPY = 3,      /* :278-287.  The reference's expression `-exp(l) * l.sum(-1) / max_entropy`
+                                        broadcasts [L,A] against [L]: defined only for episodes of L == 1 or L == A
+                                        steps, where it is reproduced as written (entry (i,j) times the row sum of step
+                                        j; mean / max over all L*A entries; golden: tests/golden/entropy.npz).  For any
+                                        other L the reference raises; those episodes score the per-step entropy
+                                        mean_t / max_t of sum_a(-p log p) / max_entropy. */
   DCD_SCORE_LEAST_CONFIDENCE = 4,    /* :289-296 */
   DCD_SCORE_MIN_MARGIN = 5,          /* :298-305 */
   DCD_SCORE_ONE_STEP_TD = 6,         /* :426-439 */

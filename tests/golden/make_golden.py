@@ -347,10 +347,63 @@ def gen_ppo():
     print("teacher_shapes.npz")
 
 
+def gen_entropy():
+    """policy_entropy (level_sampler.py:278-287): `-exp(l) * l.sum(-1) / max_entropy` broadcasts [L,A] against [L], so
+    the reference's expression is defined only for episodes of L == 1 or L == A steps (any other length raises).
+    Rollouts whose every segment has one of those two lengths, through the reference's LevelSampler; plus direct calls
+    of _average_entropy on single episodes."""
+    from level_replay import LevelSampler
+    obs_space, act_space = student_spaces()
+    A, T, B = 7, 31, 8
+    rng = np.random.default_rng(11)
+    d = synth_rollout(rng, T, B, A=A)
+    masks = np.ones((T + 1, B, 1), np.float32)
+    for b in range(B):
+        t = 0
+        while t < T:
+            left = T - t
+            L = 7 if (left >= 7 and rng.random() < 0.6) else 1
+            t += L
+            masks[t, b, 0] = 0.0                      # done closes [start, t)
+        if b % 3 == 2:
+            masks[T, b, 0] = 1.0                      # trailing PARTIAL segment (still 1 or 7 steps long)
+    d["masks"] = masks
+    cliff = np.ones_like(masks)
+    cliff[T][(masks[T] == 0) & (rng.random((B, 1)) < 0.4)] = 0.0
+    d["cliffhanger_masks"] = cliff
+    seeds = d["level_seeds"]
+    for b in range(B):                                 # a level seed is constant within an episode
+        cur = seeds[0, b, 0]
+        for t in range(T):
+            if t > 0 and masks[t, b, 0] == 0:
+                cur = int(rng.integers(1, 12))
+            seeds[t, b, 0] = cur
+    out = {f"roll_{k}": v for k, v in d.items()}
+    calls = []
+    s = LevelSampler(list(range(1, 12)), obs_space, act_space, num_actors=B, strategy="policy_entropy",
+                     score_transform="rank", temperature=0.1, staleness_coef=0.3, rho=0.5, replay_prob=0.5, alpha=1.0)
+    orig = s._partial_update_seed_score
+
+    def log(actor_index, seed, score, max_score, num_steps, done=False, _o=orig):
+        calls.append((actor_index, seed, float(score), float(max_score), num_steps, int(done)))
+        return _o(actor_index, seed, score, max_score, num_steps, done=done)
+
+    s._partial_update_seed_score = log
+    s.update_with_rollouts(_Rollouts(d, d["value_preds"]))
+    out["calls"] = np.array(calls, dtype=np.float64)
+    out["seed_scores"] = s.seed_scores.copy()
+    # direct calls on normalised log-probabilities
+    for L in (1, 7):
+        l = torch.log_softmax(torch.from_numpy(rng.standard_normal((L, A)).astype(np.float32) * 2), -1)
+        out[f"direct{L}_logits"] = l.numpy().copy()
+        out[f"direct{L}_mean_max"] = np.array(s._average_entropy(episode_logits=l))
+    np.savez_compressed(os.path.join(OUT, "entropy.npz"), **out)
+    print("entropy.npz", len(out), "calls", len(calls))
+
+
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(1)
-    gen_scans()
-    gen_sampler()
-    gen_store()
-    gen_ppo()
+    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy"]     # name the sets to (re)generate
+    for name in todo:
+        globals()["gen_" + name]()

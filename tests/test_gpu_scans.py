@@ -106,7 +106,38 @@ def test_episode_scores_match_reference_calls(strategy):
     np.testing.assert_allclose(keep["max_score"], calls[:, 3], rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("strategy", [0, 1, 2, 4, 5, 6, 7, 8])
+def test_policy_entropy_matches_reference_on_its_defined_lengths():
+    """Strategy 3 against the reference's LevelSampler (tests/golden/entropy.npz: every episode has L == 1 or L == A
+    steps, the only lengths on which level_sampler.py:283 broadcasts) and against its _average_entropy directly."""
+    from dcd_hip import scans
+    g = np.load(os.path.join(G, "entropy.npz"))
+    d = {k[len("roll_"):]: g[k] for k in g.files if k.startswith("roll_")}
+    T, B = d["rewards"].shape[:2]
+    sc = scans.EpisodeScorer(T, B, DEV)
+    sc.launch(dev(d["value_preds"]), dev(d["value_preds"]), dev(d["rewards"]), dev(d["masks"]), dev(d["cliffhanger_masks"]),
+              dev(d["level_seeds"]), dev(d["action_log_dist"]), 3, 0.995)
+    recs = sc.records()
+    assert set(recs["num_steps"]) == {1, 7}
+    keep = recs[(recs["flags"] & 2) == 0]
+    calls = g["calls"]
+    assert len(keep) == len(calls) > 40
+    assert np.array_equal(keep["actor"], calls[:, 0]) and np.array_equal(keep["seed"], calls[:, 1])
+    assert np.array_equal(keep["num_steps"], calls[:, 4]) and np.array_equal(keep["flags"] & 1, calls[:, 5])
+    np.testing.assert_allclose(keep["mean_score"], calls[:, 2], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(keep["max_score"], calls[:, 3], rtol=1e-5, atol=1e-6)
+    for L in (1, 7):
+        l = g[f"direct{L}_logits"]
+        z = torch.zeros((L + 1, 1), device=DEV)
+        m = torch.ones((L + 1, 1), device=DEV)
+        m[L] = 0
+        one = scans.EpisodeScorer(L, 1, DEV)
+        one.launch(z, z, z[:L], m, torch.ones_like(m), torch.ones((L, 1), dtype=torch.int32, device=DEV), dev(l[:, None, :]), 3, 0.995)
+        r = one.records()
+        assert len(r) == 1 and r["num_steps"][0] == L
+        np.testing.assert_allclose([r["mean_score"][0], r["max_score"][0]], g[f"direct{L}_mean_max"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("strategy", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_episode_scores_full_size_match_oracle(strategy):
     from dcd_hip import scans
     T, B, A = 256, 4096, 7
@@ -126,7 +157,7 @@ def test_episode_scores_full_size_match_oracle(strategy):
     assert len(recs) == len(ref)
     for k in ("actor", "seed", "start_t", "num_steps", "flags"):
         assert np.array_equal(recs[k], ref[k]), k
-    if strategy in (4, 5):          # expf/logf differ between device and host libm
+    if strategy in (3, 4, 5):       # expf/logf differ between device and host libm
         np.testing.assert_allclose(recs["mean_score"], ref["mean_score"], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(recs["max_score"], ref["max_score"], rtol=1e-5, atol=1e-6)
     else:

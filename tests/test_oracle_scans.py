@@ -54,6 +54,46 @@ def test_episode_records_vs_reference_calls(strategy):
     np.testing.assert_allclose(keep["max_score"], calls[:, 3], rtol=1e-6, atol=1e-7)
 
 
+def test_policy_entropy_vs_reference_on_its_defined_lengths():
+    """level_sampler.py:283 broadcasts [L,A] against [L]: defined for L in {1, A} only.  tests/golden/entropy.npz holds a
+    rollout whose every episode has one of those lengths, scored by the reference's LevelSampler, and direct calls of
+    _average_entropy; exp/log-based scores: rtol 1e-5 (host libm vs torch's vectorised exp)."""
+    g = np.load(os.path.join(G, "entropy.npz"))
+    d = {k[len("roll_"):]: g[k] for k in g.files if k.startswith("roll_")}
+    recs = orc.episode_scores(sq(d["value_preds"]), sq(d["value_preds"]), sq(d["rewards"]), sq(d["masks"]),
+                              sq(d["cliffhanger_masks"]), sq(d["level_seeds"]), d["action_log_dist"], 3, 0.995)
+    assert set(recs["num_steps"]) == {1, 7}
+    keep = recs[(recs["flags"] & 2) == 0]
+    calls = g["calls"]
+    assert len(keep) == len(calls) > 40
+    assert np.array_equal(keep["actor"], calls[:, 0]) and np.array_equal(keep["seed"], calls[:, 1])
+    assert np.array_equal(keep["num_steps"], calls[:, 4]) and np.array_equal(keep["flags"] & 1, calls[:, 5])
+    np.testing.assert_allclose(keep["mean_score"], calls[:, 2], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(keep["max_score"], calls[:, 3], rtol=1e-5, atol=1e-6)
+    for L in (1, 7):                                   # one episode on its own
+        l = g[f"direct{L}_logits"]
+        z = np.zeros((L + 1, 1), np.float32)
+        m = np.ones((L + 1, 1), np.float32)
+        m[L] = 0
+        r = orc.episode_scores(z, z, z[:L], m, np.ones_like(m), np.ones((L, 1), np.int32), l[:, None, :], 3)
+        assert len(r) == 1 and r["num_steps"][0] == L
+        np.testing.assert_allclose([r["mean_score"][0], r["max_score"][0]], g[f"direct{L}_mean_max"], rtol=1e-5, atol=1e-6)
+
+
+def test_policy_entropy_other_lengths_is_the_per_step_entropy():
+    """Lengths the reference's expression rejects: mean_t / max_t of sum_a(-p log p) / log A."""
+    rng = np.random.default_rng(0)
+    L, A = 5, 7
+    l = rng.standard_normal((L, 1, A)).astype(np.float32)
+    z = np.zeros((L + 1, 1), np.float32)
+    m = np.ones((L + 1, 1), np.float32)
+    m[L] = 0
+    r = orc.episode_scores(z, z, z[:L], m, np.ones_like(m), np.ones((L, 1), np.int32), l, 3)
+    ls = l[:, 0] - np.log(np.exp(l[:, 0].astype(np.float64)).sum(-1, keepdims=True))
+    h = (-(np.exp(ls) * ls).sum(-1) / np.log(A))
+    np.testing.assert_allclose([r["mean_score"][0], r["max_score"][0]], [h.mean(), h.max()], rtol=1e-5)
+
+
 def test_segmentation_edge_cases():
     T, B = 6, 4
     z = np.zeros((T + 1, B), np.float32)
