@@ -56,6 +56,7 @@ def parse():
                     help="also time dcd_mg_step alone at B = 65 536 and 1 048 576, where it is HBM-bound (default: on, rank 0, N=1)")
     ap.add_argument("--no-sweep", dest="sweep", action="store_false")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a shared GPU)")
+    ap.add_argument("--no-pair", action="store_true", help="step the two students' env copies in two launches per step instead of one")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the end-to-end PAIRED leg (policy nets + PPO in the loop)")
     ap.add_argument("--train-updates", type=int, default=2, help="timed AdversarialRunner.run() calls of the end-to-end leg")
     return ap.parse_args()
@@ -66,15 +67,17 @@ class PairedPass:
 
     N_CLUTTER = 25
 
-    def __init__(self, B, T, device, rank):
+    def __init__(self, B, T, device, rank, pair=True):
         import dcd_hip
+        self.pair = pair
         from dcd_hip import scans
         self.dcd_hip, self.scans = dcd_hip, scans
         self.B, self.T, self.dev, self.rank = B, T, device, rank
         self.base = rank * B
         self.eng = dcd_hip.MultiGridEngine(B, device=device, size=15, agent_view_size=5, max_steps=250,
                                            max_episode_steps=250, n_clutter=self.N_CLUTTER, choose_goal_last=1,
-                                           random_z_dim=50, engine_seed=0, env_index_base=self.base)
+                                           random_z_dim=50, engine_seed=0, env_index_base=self.base, replicas=2)
+        self.twin = self.eng.replica(1)             # the antagonist's copy of the levels (dcd_mg_step_pair)
         self.Tadv = self.N_CLUTTER + 2
         z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=device)
         # teacher rollout buffers (obs of step k+1 written by step k; adversarial_runner.py:481,515)
@@ -105,16 +108,28 @@ class PairedPass:
         for k in range(self.Tadv):
             eng.step_adversary(adv["loc"][k], dict(image_f32=adv["image"][k + 1], time_step=adv["time_step"][k + 1],
                                                    random_z=adv["random_z"][k + 1], done=adv["done"][k]))
+        # protagonist and antagonist play the teacher's levels in independent rollouts (adversarial_runner.py:709-733):
+        # each on its own copy of the env records, both advanced by ONE launch per step
+        self.twin.clone_levels(eng)
+        engines = (eng, self.twin)
         for ai, a in enumerate(self.agents):
-            eng.reset_agent(dict(image_f32=a["image"][0], dir_f32=a["direction"][0]))
+            engines[ai].reset_agent(dict(image_f32=a["image"][0], dir_f32=a["direction"][0]))
             ra(B, self.base, 3 + ai, 0, 7, self.dev, out=a["actions"], T=T)                    # synthetic student actions
-            for t in range(T):
-                eng.step(a["actions"][t], self.dcd_hip.STEP_LAST if t == T - 1 else 0, dict(
-                    obs=dict(image_f32=a["image"][t + 1], dir_f32=a["direction"][t + 1]),
-                    term_obs=dict(image_f32=a["trunc_image"][t + 1], dir_f32=a["trunc_dir"][t + 1]),
-                    reward=a["rewards"][t], done=a["done"][t], info=a["info"][t], ep_ret=a["ep_ret"][t],
-                    ep_len=a["ep_len"][t], masks=a["masks"][t + 1], bad_masks=a["bad_masks"][t + 1],
-                    cliffhanger_masks=a["cliff"][t + 1]))
+        outs = lambda a, t: dict(
+            obs=dict(image_f32=a["image"][t + 1], dir_f32=a["direction"][t + 1]),
+            term_obs=dict(image_f32=a["trunc_image"][t + 1], dir_f32=a["trunc_dir"][t + 1]),
+            reward=a["rewards"][t], done=a["done"][t], info=a["info"][t], ep_ret=a["ep_ret"][t],
+            ep_len=a["ep_len"][t], masks=a["masks"][t + 1], bad_masks=a["bad_masks"][t + 1],
+            cliffhanger_masks=a["cliff"][t + 1])
+        p, q = self.agents
+        for t in range(T):
+            flags = self.dcd_hip.STEP_LAST if t == T - 1 else 0
+            if self.pair:
+                eng.step_pair(self.twin, p["actions"][t], q["actions"][t], flags, outs(p, t), outs(q, t))
+            else:
+                eng.step(p["actions"][t], flags, outs(p, t))
+                self.twin.step(q["actions"][t], flags, outs(q, t))
+        for a in self.agents:
             self.scans.gae_returns(a["rewards"], a["value_preds"], a["masks"], a["returns"], 0.995, 0.95)
             a["scorer"].launch(a["returns"], a["value_preds"], a["rewards"], a["masks"], a["cliff"], a["level_seeds"],
                                None, self.dcd_hip.SCORE_STRATEGY["positive_value_loss"], 0.995)
@@ -214,20 +229,49 @@ def py_subproc_baseline(seconds=3.0):
                 sample=f"{steps} steps, {n} worker processes x 1 env, pure-Python object-per-cell MultiGrid over pipes, {dt:.1f}s wall")
 
 
+def kernel_source_hash():
+    """sha256 over the step kernel's sources: ties a committed PMC measurement to the code it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mg_kernels.hip", "mg_env.h"):
+        h.update(open(os.path.join(ROOT, "dcd-isaac_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(kernel_name, path=None):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this command (tools/pmc_traffic.py; counters need their own profiler runs, they cannot be read from inside the
+    benchmark).  Reported only when the file was taken on THIS kernel: same template instance, same source hash."""
+    path = path or os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "no PMC file"
+    d = json.load(open(path))
+    if d.get("kernel") != kernel_name:
+        return None, f"PMC file is for {d.get('kernel')}, not {kernel_name}"
+    if d.get("source_sha256") != kernel_source_hash():
+        return None, "PMC file predates the current kernel source (hash mismatch): re-measure"
+    return d.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT)
+
+
 def step_kernel_profile(ps, n=256):
-    """Average duration of the dominant kernel (mg_step_kernel) from HIP events attached to each
-    dispatch, on torch's current stream, over one eager student rollout of the benchmark workload."""
-    a = ps.agents[0]
-    ps.eng.reset_agent(dict(image_f32=a["image"][0], dir_f32=a["direction"][0]))
-    ps.eng.profile_begin(n)
+    """Average duration of the dominant kernel (mg_step_kernel, both students' envs per launch) from HIP events attached
+    to each dispatch, on torch's current stream, over one eager student rollout of the benchmark workload."""
+    p, q = ps.agents
+    ps.eng.reset_agent(dict(image_f32=p["image"][0], dir_f32=p["direction"][0]))
+    ps.twin.reset_agent(dict(image_f32=q["image"][0], dir_f32=q["direction"][0]))
+    outs = lambda a, t: dict(
+        obs=dict(image_f32=a["image"][t + 1], dir_f32=a["direction"][t + 1]),
+        term_obs=dict(image_f32=a["trunc_image"][t + 1], dir_f32=a["trunc_dir"][t + 1]),
+        reward=a["rewards"][t], done=a["done"][t], info=a["info"][t], ep_ret=a["ep_ret"][t],
+        ep_len=a["ep_len"][t], masks=a["masks"][t + 1], bad_masks=a["bad_masks"][t + 1],
+        cliffhanger_masks=a["cliff"][t + 1])
+    ps.eng.profile_begin(2 * n)
     for t in range(n):
         tt = t % ps.T
-        ps.eng.step(a["actions"][tt], 0, dict(
-            obs=dict(image_f32=a["image"][tt + 1], dir_f32=a["direction"][tt + 1]),
-            term_obs=dict(image_f32=a["trunc_image"][tt + 1], dir_f32=a["trunc_dir"][tt + 1]),
-            reward=a["rewards"][tt], done=a["done"][tt], info=a["info"][tt], ep_ret=a["ep_ret"][tt],
-            ep_len=a["ep_len"][tt], masks=a["masks"][tt + 1], bad_masks=a["bad_masks"][tt + 1],
-            cliffhanger_masks=a["cliff"][tt + 1]))
+        if ps.pair:
+            ps.eng.step_pair(ps.twin, p["actions"][tt], q["actions"][tt], 0, outs(p, tt), outs(q, tt))
+        else:
+            ps.eng.step(p["actions"][tt], 0, outs(p, tt))
     launches, ms = ps.eng.profile_end()
     return ms / max(launches, 1) * 1e-3          # seconds per launch
 
@@ -323,7 +367,7 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     B, T = args.envs, args.num_steps
-    ps = PairedPass(B, T, device, rank)
+    ps = PairedPass(B, T, device, rank, pair=not args.no_pair)
     stream = torch.cuda.Stream(device)
     graph = None
     with torch.cuda.stream(stream):
@@ -371,12 +415,11 @@ def main():
 
     if rank == 0:
         total_steps = ps.steps_per_pass() * world * args.steps
-        algo = B * STEP_ALGO_BYTES
+        rows = B * (2 if ps.pair else 1)                 # envs one launch of the step kernel advances
+        algo = rows * STEP_ALGO_BYTES
         achieved = algo / kernel_s / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and B == 4096:            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        kernel_name = f"mg_step_kernel<false,{ps.eng.step_epb(rows)},false,{'true' if ps.pair else 'false'}>"
+        traffic, traffic_note = pmc_traffic(kernel_name) if B == 4096 else (None, "PMC passes are taken at 4096 envs only")
         line = {
             "metric": "env-steps/sec (whole node), MultiGrid PAIRED 4096 envs/GPU",
             "value": total_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -390,9 +433,9 @@ def main():
                        "env_steps_per_pass_per_gpu": ps.steps_per_pass(),
                        "episode_records_last_pass": n_recs, "episodes_last_pass": episodes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "mg_step_kernel<false,16,false>",
-                         "algorithmic_bytes_per_launch": algo, "avg_launch_us": kernel_s * 1e6,
-                         "note": "B=4096 moves 1.76 MB per launch: latency-bound (DESIGN.md §3); roofline_large_b: the same kernel where it is HBM-bound"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note, "kernel": kernel_name,
+                         "envs_per_launch": rows, "algorithmic_bytes_per_launch": algo, "avg_launch_us": kernel_s * 1e6,
+                         "note": f"one launch moves {algo / 1e6:.2f} MB: latency-bound at this batch (DESIGN.md §3); roofline_large_b: the same kernel where it is HBM-bound"},
         }
         if sweep is not None:
             line["roofline_large_b"] = sweep

@@ -198,7 +198,7 @@ __device__ __forceinline__ void raise(uint32_t* errs, uint32_t bits, int env) {
 struct StepArgs {
   uint8_t* rec; const uint32_t* seed; Metrics* met; uint32_t* errs;
   const int64_t* actions; int flags;
-  DcdStepOut out;
+  DcdStepOut out[2];        // [1]: the second replica's outputs (dcd_mg_step_pair)
   // fused random-action mode (dcd_mg_step_random)
   int K; uint32_t action_seed, t0; int64_t env_index_base; unsigned long long* n_episodes;
   unsigned long long* stamps;   // diagnostic build only (-DDCD_STAMPS): [grid][8] s_memtime per phase
@@ -228,10 +228,14 @@ struct StepRes { float reward, ep_ret; int ep_len; uint32_t flags; uint32_t doff
 // The first four arguments repeat a.rec / a.seed / a.actions / p.B as plain scalars: with
 // -amdgpu-kernarg-preload-count they arrive in SGPRs at wave launch (struct arguments are not preloaded), so the
 // record / seed / action loads are issued without waiting for a kernarg fetch first.
-template <bool RANDOM, int EPB, bool RR>
+// PAIR: the launch steps TWO replicas of the batch (dcd_mg_step_pair: the protagonist's and the antagonist's copy of the
+// levels, records / seeds / metrics contiguous: replica 1 starts at row B).  Workgroups [0, bps) serve replica 0,
+// [bps, 2 bps) replica 1; a replica has its own action array and output set, everything else is indexed by record row.
+template <bool RANDOM, int EPB, bool RR, bool PAIR = false>
 __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel(const uint8_t* __restrict__ rec_in,
                                                                                  const uint32_t* __restrict__ seed_in,
                                                                                  const int64_t* __restrict__ actions_in, int B_in,
+                                                                                 const int64_t* __restrict__ actions1_in,
                                                                                  Params p, StepArgs a) {
   constexpr int NT = Threads<EPB>::value;
   __shared__ __attribute__((aligned(16))) uint8_t lds[EPB * LP];
@@ -240,14 +244,19 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
   __shared__ uint8_t term_valid[EPB];
   __shared__ int any_term;
   __shared__ Luts lut;
-  const int tid = threadIdx.x, env0 = blockIdx.x * EPB;
-  const int n = min(EPB, B_in - env0), env = env0 + tid;
+  const int tid = threadIdx.x;
+  int set = 0, blk = blockIdx.x;
+  if (PAIR) { const int bps = (B_in + EPB - 1) / EPB; if (blk >= bps) { set = 1; blk -= bps; } }
+  const int env0 = blk * EPB;                        // first env of this workgroup within its replica
+  const int row0 = PAIR ? set * B_in + env0 : env0;  // ... and its record row
+  const int n = min(EPB, B_in - env0), env = env0 + tid, row = row0 + tid;
+  const DcdStepOut& outs = a.out[PAIR ? set : 0];
   STAMP(0);
   // issue every independent global load up front: records, action, seed (one HBM round trip in all)
   StageBuf<EPB, NT> sb;
-  if (tid < NT) stage_load<EPB, NT>(sb, rec_in, [env0](int row) { return env0 + row; }, n, tid);
+  if (tid < NT) stage_load<EPB, NT>(sb, rec_in, [row0](int r) { return row0 + r; }, n, tid);
   int64_t act0 = 0; uint32_t seed = 0;
-  if (tid < n) { seed = seed_in[env]; if (!RANDOM) act0 = actions_in[env]; term_valid[tid] = 0; }
+  if (tid < n) { seed = seed_in[row]; if (!RANDOM) act0 = ((PAIR && set) ? actions1_in : actions_in)[env]; term_valid[tid] = 0; }
   const int OP = obs_pitch(p.V);
   if (tid == 0) any_term = 0;
   init_luts(lut, tid);
@@ -263,7 +272,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
     Env e = make_env(as_lds(lds + (live ? tid : 0) * LP), seed);
     e.cache_side();
     Metrics m = {0, 0, 0, 0}; bool mdirty = false;
-    if (RR && live && (step_flags & DCD_STEP_RESET_RANDOM)) m = a.met[env];
+    if (RR && live && (step_flags & DCD_STEP_RESET_RANDOM)) m = a.met[row];
     StepResult r = {};
     const int K = RANDOM ? a.K : 1;
     for (int k = 0; k < K; ++k) {
@@ -312,7 +321,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
       sr.flags = (uint32_t)r.done | ((uint32_t)r.info << 8) | ((uint32_t)(e.full_dirty ? 1 : 0) << 16) | ((uint32_t)(e.ctr_dirty ? 1 : 0) << 17) | ((uint32_t)min(e.nd, 2) << 20);
       sr.doff = (uint32_t)e.doff0 | ((uint32_t)e.doff1 << 16);
       res[tid] = sr;
-      if (RR && DCD_RARE(mdirty)) a.met[env] = m;
+      if (RR && DCD_RARE(mdirty)) a.met[row] = m;
       if (DCD_RARE(e.err)) raise(a.errs, e.err, env);
     }
     STAMP(3);
@@ -320,16 +329,16 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
   __syncthreads();
   STAMP(4);
   if (tid < NT) {
-    render_emit_v<EPB, NT>(lds, lut, a.out.obs, (size_t)env0, n, p, tid);     // post-auto-reset observation
+    render_emit_v<EPB, NT>(lds, lut, outs.obs, (size_t)env0, n, p, tid);      // post-auto-reset observation
     STAMP(5);
-    if (any_term) emit_staged<NT>(sterm, lut, a.out.term_obs, (size_t)env0, n, p.V, tid, term_valid);
+    if (any_term) emit_staged<NT>(sterm, lut, outs.term_obs, (size_t)env0, n, p.V, tid, term_valid);
     STAMP(6);
   } else if (tid < NT + WAVE) {                      // duty wave A: per-env scalar outputs
     const int l = tid - NT, ev = env0 + l;
     if (l < n) {
       const StepRes sr = res[l];
       const uint32_t done = sr.flags & 255, info = (sr.flags >> 8) & 255;
-      const DcdStepOut& o = a.out;
+      const DcdStepOut& o = outs;
       if (o.reward) o.reward[ev] = sr.reward;
       if (o.done) o.done[ev] = (uint8_t)done;
       if (o.info) o.info[ev] = (uint8_t)info;
@@ -340,10 +349,10 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
       if (o.cliffhanger_masks) o.cliffhanger_masks[ev] = (info & DCD_INFO_CLIFFHANGER) ? 0.f : 1.f;
     }
   } else {                                           // duty wave B: record write-back
-    const int l = tid - NT - WAVE, ev = env0 + l;
+    const int l = tid - NT - WAVE;
     if (l < n) {
       const StepRes sr = res[l];
-      uint8_t* g = a.rec + (size_t)ev * REC_BYTES;
+      uint8_t* g = a.rec + (size_t)(row0 + l) * REC_BYTES;
       const uint8_t* src = lds + l * LP;
       if ((sr.flags >> 16) & 1) {
         uint4 rows[16];
@@ -554,6 +563,16 @@ __global__ void get_metrics_kernel(int B, const Metrics* met, int32_t* ncl, int3
   if (dist) dist[i] = m.distance_to_goal;
 }
 
+// records (16 x 16 B per env), Philox keys and metrics (16 B per env) of one replica into another
+__global__ void clone_kernel(int B, const uint4* __restrict__ rec_s, uint4* __restrict__ rec_d, const uint32_t* __restrict__ seed_s,
+                             uint32_t* __restrict__ seed_d, const uint4* __restrict__ met_s, uint4* __restrict__ met_d) {
+  static_assert(sizeof(Metrics) == 16 && REC_BYTES == 256, "clone_kernel copies 16-byte units");
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < B * 16) rec_d[q] = rec_s[q];
+  else if (q < B * 17) { met_d[q - B * 16] = met_s[q - B * 16]; }
+  else if (q < B * 18) { seed_d[q - B * 17] = seed_s[q - B * 17]; }
+}
+
 __global__ void random_actions_kernel(int64_t* actions, int B, int T, long long base, uint32_t seed, uint32_t t0, int num_actions) {
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= (long long)B * T) return;
@@ -581,6 +600,10 @@ extern "C" { DCD_BIG_DECL(32) DCD_BIG_DECL(64) DCD_BIG_DECL(128) }
 struct DcdMg {
   void* big = nullptr;   // size > 15: the pitch-specific handle of mg_big.hip, everything below is unused
   int pitch = 16;
+  // replicas: R copies of the batch in ONE allocation (rec / seed / met of replica k start at row k*B); the handle
+  // dcd_mg_create returns is replica 0 and owns the memory, dcd_mg_replica hands out non-owning views of the others
+  int replicas = 1, replica = 0;
+  DcdMg* owner = nullptr;
   DcdMgConfig cfg;
   Params p;
   int device;
@@ -610,7 +633,11 @@ int fail(const char* fmt, ...) {
 
 static inline int nblk(int n) { return (n + 63) / 64; }
 // envs per workgroup of the step kernel: keep >= ~2 workgroups per CU (256 CUs) before widening
-static inline int step_epb(int B) { return B >= 64 * 512 ? 64 : (B >= 32 * 512 ? 32 : 16); }
+static inline int step_epb(int B) {
+  static const int forced = [] { const char* e = getenv("DCD_STEP_EPB"); return e ? atoi(e) : 0; }();   // diagnostic: same-box A/B
+  if (forced == 16 || forced == 32 || forced == 64) return forced;
+  return B >= 64 * 512 ? 64 : (B >= 32 * 512 ? 32 : 16);
+}
 
 static LevelArgs base_args(DcdMg* h) {
   LevelArgs a; memset(&a, 0, sizeof a);
@@ -644,6 +671,8 @@ int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out) {
   if (cfg->editor_actions < 0 || cfg->editor_actions > 2) return dcd::fail("editor_actions must be 0..2");
   if (cfg->n_clutter < 0 || cfg->n_clutter + 2 > 255) return dcd::fail("n_clutter %d out of range", cfg->n_clutter);
   if (cfg->max_steps <= 0 || cfg->max_steps > 65535 || cfg->max_episode_steps > 65535) return dcd::fail("max_steps out of range");
+  if (cfg->replicas < 0 || cfg->replicas > DCD_MAX_REPLICAS) return dcd::fail("replicas %d outside [0,%d]", cfg->replicas, DCD_MAX_REPLICAS);
+  if (cfg->replicas > 1 && cfg->size > MAX_SIZE) return dcd::fail("replicas are not available for grids above 15 x 15");
   HIP_OK(hipSetDevice(device));
   DcdMg* h = new DcdMg();
   h->cfg = *cfg; h->device = device;
@@ -665,7 +694,8 @@ int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out) {
   p.fixed_environment = cfg->fixed_environment; p.goal_noise = cfg->goal_noise; p.engine_seed = cfg->engine_seed;
   p.see_through_walls = cfg->see_through_walls != 0;
   init_reward_division(p);
-  const size_t B = (size_t)p.B;
+  h->replicas = cfg->replicas > 1 ? cfg->replicas : 1;
+  const size_t B = (size_t)p.B * h->replicas;           // every replica starts as the same empty walled grid, same seeds
   const uint32_t init[2] = {0u, 0x7fffffffu};
   hipError_t e = hipMalloc(&h->rec, B * REC_BYTES);
   if (e == hipSuccess) e = hipMalloc(&h->seed, B * 4);
@@ -673,9 +703,11 @@ int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out) {
   if (e == hipSuccess) e = hipMalloc(&h->errs, 8);
   if (e == hipSuccess) e = hipMemcpy(h->errs, init, 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(init_records_kernel, dim3((p.B + 63) / 64), dim3(64), 0, 0, p, h->rec, h->seed, h->met,
-                       (long long)cfg->env_index_base);
-    e = hipGetLastError();
+    for (int k = 0; k < h->replicas && e == hipSuccess; ++k) {
+      hipLaunchKernelGGL(init_records_kernel, dim3((p.B + 63) / 64), dim3(64), 0, 0, p, h->rec + (size_t)k * p.B * REC_BYTES,
+                         h->seed + (size_t)k * p.B, h->met + (size_t)k * p.B, (long long)cfg->env_index_base);
+      e = hipGetLastError();
+    }
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {                                          // nothing of a failed creation survives
@@ -693,10 +725,39 @@ int dcd_mg_destroy(DcdMg* h) {
     delete h;
     return rc;
   }
+  if (h->owner) { delete h; return 0; }                 // a replica view owns nothing
   (void)hipSetDevice(h->device);
   (void)hipFree(h->rec); (void)hipFree(h->seed); (void)hipFree(h->met); (void)hipFree(h->errs);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   delete h;
+  return 0;
+}
+
+int dcd_mg_replica(DcdMg* h, int32_t k, DcdMg** out) {
+  CHECK_H(h);
+  if (!out) return dcd::fail("dcd_mg_replica: null out");
+  NO_BIG(h, "dcd_mg_replica");
+  if (h->owner) return dcd::fail("dcd_mg_replica: call it on the handle dcd_mg_create returned");
+  if (k < 1 || k >= h->replicas) return dcd::fail("dcd_mg_replica: replica %d outside [1,%d)", k, h->replicas);
+  DcdMg* v = new DcdMg();
+  v->cfg = h->cfg; v->p = h->p; v->device = h->device; v->replicas = 1; v->replica = k; v->owner = h;
+  v->rec = h->rec + (size_t)k * h->p.B * REC_BYTES; v->seed = h->seed + (size_t)k * h->p.B; v->met = h->met + (size_t)k * h->p.B;
+  v->errs = h->errs;                                     // one error word per allocation
+  *out = v;
+  return 0;
+}
+
+int dcd_mg_clone_levels(DcdMg* dst, DcdMg* src, void* stream) {
+  CHECK_H(dst); CHECK_H(src);
+  NO_BIG(dst, "dcd_mg_clone_levels"); NO_BIG(src, "dcd_mg_clone_levels");
+  if (dst->p.B != src->p.B || dst->p.S != src->p.S || dst->device != src->device)
+    return dcd::fail("dcd_mg_clone_levels: handles differ in batch, grid size or device");
+  if (dst->rec == src->rec) return 0;
+  const int B = src->p.B;
+  hipLaunchKernelGGL(clone_kernel, dim3((B * 18 + 255) / 256), dim3(256), 0, (hipStream_t)stream, B,
+                     reinterpret_cast<const uint4*>(src->rec), reinterpret_cast<uint4*>(dst->rec), src->seed, dst->seed,
+                     reinterpret_cast<const uint4*>(src->met), reinterpret_cast<uint4*>(dst->met));
+  HIP_OK(hipGetLastError());
   return 0;
 }
 
@@ -783,26 +844,44 @@ int dcd_mg_mutate_level(DcdMg* h, int32_t num_edits, const DcdStudentObs* out, v
   return launch_level<OP_MUTATE>(h, a, stream);
 }
 
+// one launch over `n_sets` replicas starting at handle h (1: the plain step)
+static int launch_step(DcdMg* h, int n_sets, const int64_t* actions0, const int64_t* actions1, int32_t flags, const DcdStepOut* out0,
+                       const DcdStepOut* out1, void* stream) {
+  StepArgs a; memset(&a, 0, sizeof a);
+  a.rec = h->rec; a.seed = h->seed; a.met = h->met; a.errs = h->errs; a.actions = actions0; a.flags = flags;
+  a.stamps = h->stamps;
+  if (out0) a.out[0] = *out0;
+  if (out1) a.out[1] = *out1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) { e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1]; h->ev_used += 2; }
+  const int epb = step_epb(h->p.B * n_sets);
+  const dim3 grid(((h->p.B + epb - 1) / epb) * n_sets);
+#define DCD_LAUNCH_STEP(EPB_, RR_, PAIR_) hipExtLaunchKernelGGL((mg_step_kernel<false, EPB_, RR_, PAIR_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, (const uint8_t*)h->rec, (const uint32_t*)h->seed, actions0, h->p.B, actions1, h->p, a)
+#define DCD_LAUNCH_EPB(EPB_) do { if (n_sets == 2) { if (rr) DCD_LAUNCH_STEP(EPB_, true, true); else DCD_LAUNCH_STEP(EPB_, false, true); } \
+                                  else { if (rr) DCD_LAUNCH_STEP(EPB_, true, false); else DCD_LAUNCH_STEP(EPB_, false, false); } } while (0)
+  const bool rr = (flags & DCD_STEP_RESET_RANDOM) != 0;
+  if (epb == 16) DCD_LAUNCH_EPB(16); else if (epb == 32) DCD_LAUNCH_EPB(32); else DCD_LAUNCH_EPB(64);
+#undef DCD_LAUNCH_EPB
+#undef DCD_LAUNCH_STEP
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int dcd_mg_step(DcdMg* h, const int64_t* actions, int32_t flags, const DcdStepOut* out, void* stream) {
   CHECK_H(h);
   if (!actions) return dcd::fail("dcd_mg_step: null actions");
   if (h->big) return BIG(h, dcd_big_step, actions, flags, out, stream);
-  StepArgs a; memset(&a, 0, sizeof a);
-  a.rec = h->rec; a.seed = h->seed; a.met = h->met; a.errs = h->errs; a.actions = actions; a.flags = flags;
-  a.stamps = h->stamps;
-  if (out) a.out = *out;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) { e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1]; h->ev_used += 2; }
-  const int epb = step_epb(h->p.B);
-  const dim3 grid((h->p.B + epb - 1) / epb);
-#define DCD_LAUNCH_STEP(EPB_, RR_) hipExtLaunchKernelGGL((mg_step_kernel<false, EPB_, RR_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, (const uint8_t*)h->rec, (const uint32_t*)h->seed, actions, h->p.B, h->p, a)
-  const bool rr = (flags & DCD_STEP_RESET_RANDOM) != 0;
-  if (epb == 16) { if (rr) DCD_LAUNCH_STEP(16, true); else DCD_LAUNCH_STEP(16, false); }
-  else if (epb == 32) { if (rr) DCD_LAUNCH_STEP(32, true); else DCD_LAUNCH_STEP(32, false); }
-  else { if (rr) DCD_LAUNCH_STEP(64, true); else DCD_LAUNCH_STEP(64, false); }
-#undef DCD_LAUNCH_STEP
-  HIP_OK(hipGetLastError());
-  return 0;
+  return launch_step(h, 1, actions, nullptr, flags, out, nullptr, stream);
+}
+
+int dcd_mg_step_pair(DcdMg* h0, DcdMg* h1, const int64_t* actions0, const int64_t* actions1, int32_t flags,
+                     const DcdStepOut* out0, const DcdStepOut* out1, void* stream) {
+  CHECK_H(h0); CHECK_H(h1);
+  if (!actions0 || !actions1) return dcd::fail("dcd_mg_step_pair: null actions");
+  NO_BIG(h0, "dcd_mg_step_pair");
+  if (h1->owner != (h0->owner ? h0->owner : h0) || h1->replica != h0->replica + 1)
+    return dcd::fail("dcd_mg_step_pair: the handles must be consecutive replicas of one dcd_mg_create (replicas >= 2)");
+  return launch_step(h0, 2, actions0, actions1, flags, out0, out1, stream);
 }
 
 // diagnostic builds (-DDCD_STAMPS) only; not part of include/dcd_hip.h
@@ -846,10 +925,10 @@ int dcd_mg_step_random(DcdMg* h, uint32_t action_seed, uint32_t t0, int32_t K, i
   a.rec = h->rec; a.seed = h->seed; a.met = h->met; a.errs = h->errs; a.flags = flags;
   a.K = K; a.action_seed = action_seed; a.t0 = t0; a.env_index_base = h->cfg.env_index_base;
   a.n_episodes = reinterpret_cast<unsigned long long*>(n_episodes);
-  if (out) a.out = *out;
+  if (out) a.out[0] = *out;
   const int epb = step_epb(h->p.B);
   const dim3 grid((h->p.B + epb - 1) / epb);
-#define DCD_LAUNCH_STEP(EPB_, RR_) hipLaunchKernelGGL((mg_step_kernel<true, EPB_, RR_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, (const uint8_t*)h->rec, (const uint32_t*)h->seed, (const int64_t*)nullptr, h->p.B, h->p, a)
+#define DCD_LAUNCH_STEP(EPB_, RR_) hipLaunchKernelGGL((mg_step_kernel<true, EPB_, RR_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, (const uint8_t*)h->rec, (const uint32_t*)h->seed, (const int64_t*)nullptr, h->p.B, (const int64_t*)nullptr, h->p, a)
   const bool rr = (flags & DCD_STEP_RESET_RANDOM) != 0;
   if (epb == 16) { if (rr) DCD_LAUNCH_STEP(16, true); else DCD_LAUNCH_STEP(16, false); }
   else if (epb == 32) { if (rr) DCD_LAUNCH_STEP(32, true); else DCD_LAUNCH_STEP(32, false); }

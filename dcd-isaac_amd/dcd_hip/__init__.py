@@ -26,7 +26,8 @@ class MgConfig(C.Structure):
                 ("resample_n_clutter", C.c_int32), ("choose_goal_last", C.c_int32),
                 ("see_through_walls", C.c_int32), ("random_z_dim", C.c_int32),
                 ("editor_actions", C.c_int32), ("fixed_environment", C.c_int32),
-                ("goal_noise", C.c_float), ("engine_seed", C.c_uint32), ("env_index_base", C.c_int64)]
+                ("goal_noise", C.c_float), ("engine_seed", C.c_uint32), ("env_index_base", C.c_int64),
+                ("replicas", C.c_int32), ("reserved", C.c_int32)]
 
 
 class StudentObs(C.Structure):
@@ -66,6 +67,7 @@ SCORE_STRATEGY = {"value_l1": 0, "positive_value_loss": 1, "signed_value_loss": 
                   "policy_entropy": 3, "least_confidence": 4, "min_margin": 5, "one_step_td_error": 6,
                   "uniform": 7, "grounded_signed_value_loss": 8, "grounded_positive_value_loss": 8}
 
+ABI_VERSION = 2
 _lib = None
 
 
@@ -86,7 +88,7 @@ def lib():
                 "(or __graft_entry__.build()).  There is no CPU fallback.")
         _lib = C.CDLL(LIB_PATH)
         _lib.dcd_last_error.restype = C.c_char_p
-        if _lib.dcd_abi_version() != 1:
+        if _lib.dcd_abi_version() != ABI_VERSION:
             raise DcdHipError("libdcd_hip.so ABI version mismatch")
     return _lib
 

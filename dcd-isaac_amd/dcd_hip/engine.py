@@ -12,7 +12,7 @@ from . import (AdvObs, DcdHipError, ERR_BITS, MgConfig, StepOut, StudentObs, che
 
 _CFG_DEFAULTS = dict(size=15, agent_view_size=5, max_steps=250, max_episode_steps=250, n_clutter=50,
                      resample_n_clutter=0, choose_goal_last=0, see_through_walls=1, random_z_dim=50,
-                     editor_actions=2, fixed_environment=0, goal_noise=0.0, engine_seed=0, env_index_base=0)
+                     editor_actions=2, fixed_environment=0, goal_noise=0.0, engine_seed=0, env_index_base=0, replicas=1)
 
 _STUDENT_KEYS = ("image_u8", "dir_u8", "image_f32", "dir_f32")
 _ADV_KEYS = ("image_u8", "image_f32", "time_step", "random_z")
@@ -40,8 +40,35 @@ class MultiGridEngine:
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         check(lib().dcd_mg_create(C.byref(self.cfg), C.c_int(index), C.byref(h)))
         self._h = h
+        self._views = []
+
+    def replica(self, k):
+        """Replica k (1 <= k < replicas) of this batch as an engine of its own: a second copy of the B env records in
+        the same allocation (dcd_mg_replica).  `clone_levels` copies a level set into it, `step_pair` advances two
+        consecutive replicas in one launch."""
+        h = C.c_void_p()
+        check(lib().dcd_mg_replica(self._h, C.c_int32(int(k)), C.byref(h)))
+        v = object.__new__(MultiGridEngine)
+        v.device, v.cfg, v.B, v.S, v.V, v.Z, v.n_adv_actions = self.device, self.cfg, self.B, self.S, self.V, self.Z, self.n_adv_actions
+        v._h, v._views, v._owner = h, [], self
+        self._views.append(v)
+        return v
+
+    def clone_levels(self, src):
+        """self := src (grids, agent / episode state, Philox keys and counters, metrics)."""
+        check(lib().dcd_mg_clone_levels(self._h, src._h, stream_ptr()))
+
+    def step_pair(self, other, actions, other_actions, flags=0, out=None, other_out=None):
+        """dcd_mg_step of this replica and the next one (`other`) in ONE launch."""
+        st0, st1 = self._step_struct(out), self._step_struct(other_out)
+        check(lib().dcd_mg_step_pair(self._h, other._h, ptr(actions, torch.int64, self.B, "actions"),
+                                     ptr(other_actions, torch.int64, self.B, "other_actions"), C.c_int32(flags),
+                                     C.byref(st0), C.byref(st1), stream_ptr()))
+        return out, other_out
 
     def close(self):
+        for v in getattr(self, "_views", []):
+            v.close()
         if getattr(self, "_h", None):
             lib().dcd_mg_destroy(self._h)
             self._h = None
@@ -207,6 +234,11 @@ class MultiGridEngine:
                                        C.c_int32(flags), C.byref(st),
                                        ptr(n_episodes, torch.int64, 1, "n_episodes"), stream_ptr()))
         return out
+
+    @staticmethod
+    def step_epb(rows):
+        """Envs per workgroup the step kernel picks for a launch over `rows` env records (mg_kernels.hip::step_epb)."""
+        return 64 if rows >= 64 * 512 else (32 if rows >= 32 * 512 else 16)
 
     def profile_begin(self, capacity):
         check(lib().dcd_mg_profile_begin(self._h, C.c_int32(capacity)))

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DCD_ABI_VERSION 1
+#define DCD_ABI_VERSION 2
 
 /* ---- cell encoding constants (gym-minigrid 1.0.1 OBJECT_TO_IDX etc.; SURVEY
  * Appendix A.2; used by envs/multigrid/multigrid.py:58,76-101) ------------- */
@@ -95,7 +95,12 @@ typedef struct DcdMgConfig {
   float    goal_noise;
   uint32_t engine_seed;         /* Philox key word 1 (args.seed) */
   int64_t  env_index_base;      /* global index of local env 0 (rank * B): default per-env seed */
+  int32_t  replicas;            /* 0/1: one copy of the batch.  R > 1: R copies in one allocation (dcd_mg_replica,
+                                   dcd_mg_step_pair): PAIRED's protagonist and antagonist play the same levels in
+                                   independent rollouts (adversarial_runner.py:709-733) */
+  int32_t  reserved;
 } DcdMgConfig;
+#define DCD_MAX_REPLICAS 4
 
 typedef struct DcdMg DcdMg;     /* opaque: one per (device, env batch) */
 
@@ -143,6 +148,14 @@ int  dcd_abi_version(void);
  * `device` is the HIP device ordinal.  Allocates B × 256-byte env records. */
 int dcd_mg_create(const DcdMgConfig* cfg, int device, DcdMg** out);
 int dcd_mg_destroy(DcdMg* h);
+/* Replica k (1 <= k < cfg.replicas) of the batch behind `h` (the handle dcd_mg_create returned, which is replica 0):
+ * a non-owning view that every other entry point accepts like a handle of its own; destroy it before `h`. */
+int dcd_mg_replica(DcdMg* h, int32_t k, DcdMg** out);
+/* dst := src (grids, start / goal cells, agent and episode state, Philox keys and draw counters, metrics).  In the
+ * reference protagonist and antagonist step the SAME env objects one rollout after the other
+ * (adversarial_runner.py:709-733); each rollout starts with reset_agent (:484), so on levels made of walls and a goal
+ * (everything the teacher, reset_random and the editor can build) playing two copies side by side is the same game. */
+int dcd_mg_clone_levels(DcdMg* dst, DcdMg* src, void* stream);
 /* venv.set_seed(seeds) → MultiGridEnv.seed (parallel_wrappers.py:414-415,
  * multigrid.py:465-468).  seeds: device int64[B]; resets each env's draw counter. */
 int dcd_mg_set_seed(DcdMg* h, const int64_t* seeds, void* stream);
@@ -189,6 +202,11 @@ int dcd_mg_mutate_level(DcdMg* h, int32_t num_edits, const DcdStudentObs* out, v
  * when DCD_STEP_LAST].  actions: int64[B]. */
 int dcd_mg_step(DcdMg* h, const int64_t* actions, int32_t flags, const DcdStepOut* out,
                 void* stream);
+/* dcd_mg_step of two consecutive replicas in ONE launch (h1 = replica k+1 of h0's allocation): the two independent
+ * agent_rollout calls of a PAIRED update (adversarial_runner.py:709-733) advance in lock-step, each with its own
+ * action array and output set.  Identical results to the two dcd_mg_step calls. */
+int dcd_mg_step_pair(DcdMg* h0, DcdMg* h1, const int64_t* actions0, const int64_t* actions1, int32_t flags,
+                     const DcdStepOut* out0, const DcdStepOut* out1, void* stream);
 
 /* Per-launch timing of the step kernel for the roofline line of bench.py: between begin and end
  * every dcd_mg_step launch on this handle is bracketed by HIP events attached to the dispatch

@@ -682,6 +682,11 @@ OrcMg* orc_mg_create(const DcdMgConfig* cfg) {
   return h;
 }
 void orc_mg_destroy(OrcMg* h) { if (h) { free(h->envs); free(h); } }
+/* dcd_mg_clone_levels: the env objects themselves are copied (grid, agent, counters, RNG state, metrics) */
+void orc_mg_clone_levels(OrcMg* dst, const OrcMg* src) {
+  if (dst != src && dst->cfg.num_envs == src->cfg.num_envs)
+    memcpy(dst->envs, src->envs, (size_t)src->cfg.num_envs * sizeof(Env));
+}
 
 void orc_mg_set_seed(OrcMg* h, const int64_t* seeds) {
   for (int b = 0; b < h->cfg.num_envs; ++b) { h->envs[b].seed = (uint32_t)seeds[b]; h->envs[b].ctr = 0; }

@@ -28,7 +28,8 @@ class MgConfig(C.Structure):
                 ("resample_n_clutter", C.c_int32), ("choose_goal_last", C.c_int32),
                 ("see_through_walls", C.c_int32), ("random_z_dim", C.c_int32),
                 ("editor_actions", C.c_int32), ("fixed_environment", C.c_int32),
-                ("goal_noise", C.c_float), ("engine_seed", C.c_uint32), ("env_index_base", C.c_int64)]
+                ("goal_noise", C.c_float), ("engine_seed", C.c_uint32), ("env_index_base", C.c_int64),
+                ("replicas", C.c_int32), ("reserved", C.c_int32)]
 
 
 class StudentObs(C.Structure):
@@ -107,6 +108,10 @@ class OracleMg:
         if getattr(self, "h", None):
             self._fn("destroy")(self.h)
             self.h = None
+
+    def clone_levels(self, src):
+        """self := src, every env object with all of its state (the second copy of a PAIRED level set)."""
+        self._fn("clone_levels")(self.h, src.h)
 
     # -- buffers
     def _student(self, n=None):

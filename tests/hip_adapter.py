@@ -13,14 +13,33 @@ def _np(d):
 
 
 class HipMg:
-    def __init__(self, device="cuda:0", **cfg):
+    def __init__(self, device="cuda:0", engine=None, **cfg):
+        """engine: wrap an existing MultiGridEngine (a replica view) instead of creating one."""
         full = dict(orc.DEFAULT_CFG)
         full.update(cfg)
         self.cfg = orc.make_config(**full)
         self.B, self.S, self.V, self.Z = full["num_envs"], full["size"], full["agent_view_size"], full["random_z_dim"]
         self.dev = torch.device(device)
         n = full.pop("num_envs")
-        self.eng = dcd_hip.MultiGridEngine(n, device=device, **full)
+        self.eng = engine if engine is not None else dcd_hip.MultiGridEngine(n, device=device, **full)
+
+    def replica(self, k):
+        cfg = {f[0]: getattr(self.cfg, f[0]) for f in self.cfg._fields_ if f[0] != "reserved"}
+        return HipMg(device=str(self.dev), engine=self.eng.replica(k), **cfg)
+
+    def clone_levels(self, src):
+        self.eng.clone_levels(src.eng)
+
+    def step_pair(self, other, a0, a1, flags=0, term0=None, term1=None):
+        outs = []
+        for h, term in ((self, term0), (other, term1)):
+            o = h.eng.step_buffers()
+            if term is not None:
+                for k, v in term.items():
+                    o["term_obs"][k].copy_(torch.as_tensor(v))
+            outs.append(o)
+        self.eng.step_pair(other.eng, self._t(a0, torch.int64), self._t(a1, torch.int64), flags, outs[0], outs[1])
+        return _np(outs[0]), _np(outs[1])
 
     def _t(self, a, dtype):
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.dev)

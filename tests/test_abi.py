@@ -27,12 +27,12 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
     lib.dcd_abi_version.restype = ctypes.c_int
-    assert lib.dcd_abi_version() == 1
+    assert lib.dcd_abi_version() == dcd_hip.ABI_VERSION == 2
 
 
 def test_python_structs_match_header_layout():
     import dcd_hip
-    assert ctypes.sizeof(dcd_hip.MgConfig) == 64          # 14 x 4 + 8
+    assert ctypes.sizeof(dcd_hip.MgConfig) == 72          # 14 x 4 + 8 + 2 x 4
     assert ctypes.sizeof(dcd_hip.StudentObs) == 32 and ctypes.sizeof(dcd_hip.AdvObs) == 32
     assert ctypes.sizeof(dcd_hip.StepOut) == 32 + 5 * 8 + 32 + 3 * 8
 

@@ -73,6 +73,53 @@ def test_paired_shape_rollout_bitexact():
     mg_diff.compare_state(x, y, "after rollout")
 
 
+@pytest.mark.parametrize("B,kw", [(130, dict(n_clutter=25, choose_goal_last=1, max_episode_steps=30)),
+                                  (4096, dict(n_clutter=25, choose_goal_last=1)),
+                                  (77, dict(size=10, n_clutter=30, max_steps=200, max_episode_steps=40, agent_view_size=7, see_through_walls=0)),
+                                  (8192 + 37, dict(n_clutter=25, choose_goal_last=1, max_episode_steps=25)),
+                                  (16384 + 5, dict(n_clutter=25, choose_goal_last=1, max_episode_steps=25))])
+def test_step_pair_matches_oracle(B, kw):
+    """dcd_mg_step_pair: two replicas of the batch (the protagonist's and the antagonist's copy of the teacher's levels)
+    advanced in ONE launch with different actions == two oracle batches stepped one after the other.  Every output
+    and the full state of both, with ragged last workgroups, all three workgroup widths, the reset-random and
+    last-step variants, and level ops applied to one replica only in between."""
+    from tests.hip_adapter import HipMg
+    cfg = dict(num_envs=B, engine_seed=21, env_index_base=100)
+    cfg.update(kw)
+    x0, x1 = orc.OracleMg(**cfg), orc.OracleMg(**cfg)
+    y0 = HipMg(replicas=2, **cfg)
+    y1 = y0.replica(1)
+    rng = np.random.default_rng(B)
+    mg_diff.compare_state(x1, y1, "replica after create")
+    n_adv = cfg["n_clutter"] + 2
+    interior = (x0.S - 2) ** 2
+    x0.reset(); y0.reset()
+    for k in range(n_adv):
+        loc = rng.integers(0, interior, B)
+        x0.step_adversary(loc); y0.step_adversary(loc)
+    x1.clone_levels(x0); y1.clone_levels(y0)
+    mg_diff.compare_state(x1, y1, "clone")
+    mg_diff.assert_same(x0.reset_agent(), y0.reset_agent(), "reset_agent 0")
+    mg_diff.assert_same(x1.reset_agent(), y1.reset_agent(), "reset_agent 1")
+    t0 = t1 = u0 = u1 = None
+    T = 60 if B <= 4096 else 30
+    for t in range(T):
+        a0 = rng.choice(7, size=B, p=[0.15, 0.15, 0.5, 0.05, 0.05, 0.05, 0.05])
+        a1 = rng.choice(7, size=B, p=[0.2, 0.2, 0.4, 0.05, 0.05, 0.05, 0.05])
+        flags = (1 if t % 7 == 3 else 0) | (2 if t == T - 1 else 0)
+        o0, o1 = x0.step(a0, flags, t0), x1.step(a1, flags, t1)
+        p0, p1 = y0.step_pair(y1, a0, a1, flags, u0, u1)
+        t0, t1, u0, u1 = o0["term_obs"], o1["term_obs"], p0["term_obs"], p1["term_obs"]
+        mg_diff.assert_same(o0, p0, f"pair step {t} replica 0")
+        mg_diff.assert_same(o1, p1, f"pair step {t} replica 1")
+        if t == T // 2:                                   # a level op on ONE replica: the other must not move
+            enc = mg_diff.random_encodings(rng, B, x0.S, exotic=True)
+            mg_diff.assert_same(x1.reset_to_encoding(enc), y1.reset_to_encoding(enc), "encoding on replica 1")
+        if t % 10 == 0 or t == T - 1:
+            mg_diff.compare_state(x0, y0, f"pair step {t} replica 0")
+            mg_diff.compare_state(x1, y1, f"pair step {t} replica 1")
+
+
 def test_fused_random_steps_match_single_steps():
     """dcd_mg_step_random(K) == K single dcd_mg_step calls with the same Philox actions."""
     import torch
