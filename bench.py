@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 # algorithmic bytes per env-step of dcd_mg_step as benchmarked (fp32 CHW obs variant):
 # action 8 + dyn state r/w 2*16 + 5x5x3 window read 75 + <=2 cell writes 6 + obs 300+4 (f32 image + dir)
 # + reward 4 + done 1  = 430
-STEP_ALGO_BYTES = 430
+STEP_ALGO_BYTES = {"f32": 430, "u8": 202}     # the u8 variant writes obs as 75 + 1 bytes
 
 
 def parse():
@@ -56,6 +56,8 @@ def parse():
                     help="also time dcd_mg_step alone at B = 65 536 and 1 048 576, where it is HBM-bound (default: on, rank 0, N=1)")
     ap.add_argument("--no-sweep", dest="sweep", action="store_false")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a shared GPU)")
+    ap.add_argument("--obs", choices=["f32", "u8"], default="f32",
+                    help="student observations written by the step: fp32 CHW / 10 (what the nets read) or the raw u8 encoding")
     ap.add_argument("--no-pair", action="store_true", help="step the two students' env copies in two launches per step instead of one")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the end-to-end PAIRED leg (policy nets + PPO in the loop)")
     ap.add_argument("--train-updates", type=int, default=2, help="timed AdversarialRunner.run() calls of the end-to-end leg")
@@ -67,9 +69,10 @@ class PairedPass:
 
     N_CLUTTER = 25
 
-    def __init__(self, B, T, device, rank, pair=True):
+    def __init__(self, B, T, device, rank, pair=True, obs="f32"):
         import dcd_hip
-        self.pair = pair
+        self.pair, self.obs = pair, obs
+        self.img_key, self.dir_key = ("image_u8", "dir_u8") if obs == "u8" else ("image_f32", "dir_f32")
         from dcd_hip import scans
         self.dcd_hip, self.scans = dcd_hip, scans
         self.B, self.T, self.dev, self.rank = B, T, device, rank
@@ -87,8 +90,13 @@ class PairedPass:
         gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
         self.agents = []
         for _ in range(2):
-            a = dict(image=z(T + 1, B, 3, 5, 5), direction=z(T + 1, B, 1), trunc_image=z(T + 1, B, 3, 5, 5),
-                     trunc_dir=z(T + 1, B, 1), rewards=z(T, B), masks=torch.ones(T + 1, B, device=device),
+            if obs == "u8":           # raw encodings as the env emits them: [vx][vy][c] bytes + a direction byte
+                o = dict(image=z(T + 1, B, 5, 5, 3, dt=torch.uint8), direction=z(T + 1, B, dt=torch.uint8),
+                         trunc_image=z(T + 1, B, 5, 5, 3, dt=torch.uint8), trunc_dir=z(T + 1, B, dt=torch.uint8))
+            else:                     # preprocessed as VecPreprocessImageWrapper hands them to the nets: fp32 CHW / 10
+                o = dict(image=z(T + 1, B, 3, 5, 5), direction=z(T + 1, B, 1), trunc_image=z(T + 1, B, 3, 5, 5),
+                         trunc_dir=z(T + 1, B, 1))
+            a = dict(**o, rewards=z(T, B), masks=torch.ones(T + 1, B, device=device),
                      bad_masks=torch.ones(T + 1, B, device=device), cliff=torch.ones(T + 1, B, device=device),
                      value_preds=torch.randn(T + 1, B, generator=gen).to(device), returns=z(T + 1, B),
                      actions=z(T, B, dt=torch.int64), level_seeds=z(T, B, dt=torch.int32),
@@ -113,14 +121,9 @@ class PairedPass:
         self.twin.clone_levels(eng)
         engines = (eng, self.twin)
         for ai, a in enumerate(self.agents):
-            engines[ai].reset_agent(dict(image_f32=a["image"][0], dir_f32=a["direction"][0]))
+            engines[ai].reset_agent({self.img_key: a["image"][0], self.dir_key: a["direction"][0]})
             ra(B, self.base, 3 + ai, 0, 7, self.dev, out=a["actions"], T=T)                    # synthetic student actions
-        outs = lambda a, t: dict(
-            obs=dict(image_f32=a["image"][t + 1], dir_f32=a["direction"][t + 1]),
-            term_obs=dict(image_f32=a["trunc_image"][t + 1], dir_f32=a["trunc_dir"][t + 1]),
-            reward=a["rewards"][t], done=a["done"][t], info=a["info"][t], ep_ret=a["ep_ret"][t],
-            ep_len=a["ep_len"][t], masks=a["masks"][t + 1], bad_masks=a["bad_masks"][t + 1],
-            cliffhanger_masks=a["cliff"][t + 1])
+        outs = self.step_outs
         p, q = self.agents
         for t in range(T):
             flags = self.dcd_hip.STEP_LAST if t == T - 1 else 0
@@ -136,6 +139,14 @@ class PairedPass:
             self.scans.rollout_return_stats(a["ep_ret"], a["info"], a["mean_ret"], a["max_ret"], a["n_eps"])
         p, q = self.agents
         self.scans.env_return(p["mean_ret"], p["max_ret"], q["mean_ret"], q["max_ret"], mode=0, out=self.regret)
+
+    def step_outs(self, a, t):
+        ik, dk = self.img_key, self.dir_key
+        return dict(obs={ik: a["image"][t + 1], dk: a["direction"][t + 1]},
+                    term_obs={ik: a["trunc_image"][t + 1], dk: a["trunc_dir"][t + 1]},
+                    reward=a["rewards"][t], done=a["done"][t], info=a["info"][t], ep_ret=a["ep_ret"][t],
+                    ep_len=a["ep_len"][t], masks=a["masks"][t + 1], bad_masks=a["bad_masks"][t + 1],
+                    cliffhanger_masks=a["cliff"][t + 1])
 
     def steps_per_pass(self):
         return 2 * self.B * self.T + self.B * self.Tadv
@@ -257,14 +268,9 @@ def step_kernel_profile(ps, n=256):
     """Average duration of the dominant kernel (mg_step_kernel, both students' envs per launch) from HIP events attached
     to each dispatch, on torch's current stream, over one eager student rollout of the benchmark workload."""
     p, q = ps.agents
-    ps.eng.reset_agent(dict(image_f32=p["image"][0], dir_f32=p["direction"][0]))
-    ps.twin.reset_agent(dict(image_f32=q["image"][0], dir_f32=q["direction"][0]))
-    outs = lambda a, t: dict(
-        obs=dict(image_f32=a["image"][t + 1], dir_f32=a["direction"][t + 1]),
-        term_obs=dict(image_f32=a["trunc_image"][t + 1], dir_f32=a["trunc_dir"][t + 1]),
-        reward=a["rewards"][t], done=a["done"][t], info=a["info"][t], ep_ret=a["ep_ret"][t],
-        ep_len=a["ep_len"][t], masks=a["masks"][t + 1], bad_masks=a["bad_masks"][t + 1],
-        cliffhanger_masks=a["cliff"][t + 1])
+    ps.eng.reset_agent({ps.img_key: p["image"][0], ps.dir_key: p["direction"][0]})
+    ps.twin.reset_agent({ps.img_key: q["image"][0], ps.dir_key: q["direction"][0]})
+    outs = ps.step_outs
     ps.eng.profile_begin(2 * n)
     for t in range(n):
         tt = t % ps.T
@@ -293,7 +299,7 @@ def sweep_large_b(device, sizes=(65536, 1048576), iters=30):
         n, ms = eng.profile_end()
         dt = ms / n * 1e-3
         res.append(dict(envs=B, us_per_launch=dt * 1e6, env_steps_per_s=B / dt,
-                        achieved_GBs=B * STEP_ALGO_BYTES / dt / 1e9, frac=B * STEP_ALGO_BYTES / dt / 1e9 / HBM_PEAK_GBS))
+                        achieved_GBs=B * STEP_ALGO_BYTES["f32"] / dt / 1e9, frac=B * STEP_ALGO_BYTES["f32"] / dt / 1e9 / HBM_PEAK_GBS))
         eng.close()
         del out
         torch.cuda.empty_cache()
@@ -367,7 +373,7 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     B, T = args.envs, args.num_steps
-    ps = PairedPass(B, T, device, rank, pair=not args.no_pair)
+    ps = PairedPass(B, T, device, rank, pair=not args.no_pair, obs=args.obs)
     stream = torch.cuda.Stream(device)
     graph = None
     with torch.cuda.stream(stream):
@@ -416,7 +422,7 @@ def main():
     if rank == 0:
         total_steps = ps.steps_per_pass() * world * args.steps
         rows = B * (2 if ps.pair else 1)                 # envs one launch of the step kernel advances
-        algo = rows * STEP_ALGO_BYTES
+        algo = rows * STEP_ALGO_BYTES[ps.obs]
         achieved = algo / kernel_s / 1e9
         kernel_name = f"mg_step_kernel<false,{ps.eng.step_epb(rows)},false,{'true' if ps.pair else 'false'}>"
         traffic, traffic_note = pmc_traffic(kernel_name) if B == 4096 else (None, "PMC passes are taken at 4096 envs only")

@@ -118,11 +118,14 @@ class AdversarialRunner:
         self._done_buf = torch.zeros(B, dtype=torch.uint8, device=self.device)
         self._seeds_dev = torch.full((B, 1), -1, dtype=torch.int32, device=self.device)
         # HIP graphs.  DCD_HIP_GRAPHS=1 (default): student rollouts whose policy step runs on the fused HIP path
-        # (dcd_hip.policy: 4 kernel nodes + 1 GEMM node per step) are captured in chunks of GRAPH_CHUNK steps and
+        # (dcd_hip.policy: 4 kernel nodes + 1 GEMM node per step) are captured into one graph per rollout and
         # replayed: 17.9 -> 15.5 ms per 256-step rollout at B = 4096.  =2 also captures rollouts whose policy runs
-        # as PyTorch modules (teacher, unsupported nets: ~45 nodes per step; capture took minutes on ROCm 7.2).
+        # as PyTorch modules (teacher, unsupported nets: ~45 nodes per step).
         # =0: always eager.  Replay rollouts that re-sample levels on the host per step always stay eager.
         mode = os.environ.get("DCD_HIP_GRAPHS", "1")
+        # DCD_PAIR_ROLLOUT=1 (default): in a PAIRED update without level replay the protagonist's and the antagonist's
+        # rollouts advance in lock-step, ONE env-step launch for both (dcd_mg_step_pair) on two copies of the levels.
+        self.pair_rollouts = os.environ.get("DCD_PAIR_ROLLOUT", "1") != "0" and self.device.type == "cuda"
         self.use_hip_graphs = mode in ("1", "2") and self.device.type == "cuda"
         self.graph_pytorch_nets = mode == "2"       # also capture rollouts whose policy runs as PyTorch modules
         self._graphs = {}
@@ -293,11 +296,16 @@ class AdversarialRunner:
         return self._default_level_sampler.sample_replay_decision()
 
     # ---- rollouts --------------------------------------------------------------------------------
-    GRAPH_CHUNK = 32          # rollout steps per HIP graph (~1.4k kernel nodes; 10k-node graphs proved unstable)
+    # Rollout steps per HIP graph.  A whole rollout is ONE graph: a fused 256-step student rollout is ~1.5k kernel nodes, a
+    # rollout of PyTorch modules ~12k; graphs of 100k kernel nodes capture and replay correctly on ROCm 7.2, at ~160k
+    # hipStreamEndCapture crashes on the host (tools/graph_assert_probe.py), hence the cap for very long rollouts.  (Round 1
+    # chunked to 32 steps after a GPU abort "with 10k-node graphs"; the abort had nothing to do with graph size — see
+    # models/distributions.py::FixedCategorical.sample and DESIGN.md §8.)
+    GRAPH_CHUNK = 2048
 
     def _graphed(self, key, num_steps, fn):
-        """fn(t0, t1) issues rollout steps [t0, t1).  First call: eager (warm-up); second: captured into one
-        HIP graph per GRAPH_CHUNK steps and replayed; afterwards: replay only."""
+        """fn(t0, t1) issues rollout steps [t0, t1).  First call: eager (warm-up); second: captured (one HIP graph per
+        GRAPH_CHUNK steps, i.e. one graph) and replayed; afterwards: replay only."""
         if not self.use_hip_graphs:
             return fn(0, num_steps)
         state = self._graphs.get(key)
@@ -457,8 +465,63 @@ class AdversarialRunner:
                 self._resample_finished_levels(st, step, level_sampler, rollout_info)
             st.advance()
 
+    def _paired_student_rollouts(self, agents, num_steps, track_seeds):
+        """The protagonist's and the antagonist's rollouts of one update (adversarial_runner.py:709-733: two independent
+        `agent_rollout` calls on the teacher's levels, each starting with reset_agent :484) in lock-step: per step both
+        policies act, then ONE launch advances both copies of the envs.  Requires levels made of walls and a goal
+        (what the teacher builds): then the second rollout sees exactly the level the first one started from, as it does
+        in the reference, where reset_agent restores the agent and nothing else can have changed."""
+        if track_seeds:
+            self._seeds_dev.copy_(torch.tensor(self.current_level_seeds, dtype=torch.int32).view(-1, 1))
+        fused = [self._fused_actor(a) if self.is_discrete_actions else None for a in agents]
+        for f in fused:
+            if f is not None:
+                f.begin_rollout(num_steps)
+        body = lambda t0, t1: self._paired_rollout_body(agents, num_steps, t0, t1, track_seeds)
+        if all(f is not None for f in fused) or self.graph_pytorch_nets:
+            key = ("pair", id(agents[0]), id(agents[1]), num_steps, track_seeds) + tuple(bool(a.actor_critic.random) for a in agents)
+            self._graphed(key, num_steps, body)
+        else:
+            body(0, num_steps)
+        for a in agents:
+            a.storage.step = 0
+        self.venv.raise_errors()
+
+    def _paired_rollout_body(self, agents, num_steps, t0, t1, track_seeds):
+        args, venv = self.args, self.venv
+        sts = [a.storage for a in agents]
+        if t0 == 0:
+            venv.clone_to_twin()
+            venv.reset_agent_device(sts[0].student_obs_out(0))
+            venv.reset_agent_twin_device(sts[1].student_obs_out(0))
+        fused = [self._fused_actor(a) if self.is_discrete_actions else None for a in agents]
+        for st in sts:
+            st.step = t0
+        for step in range(t0, t1):
+            for agent, st, f in zip(agents, sts, fused):
+                if f is not None:
+                    f.act_storage(st, step)
+                    if track_seeds:
+                        st.level_seeds[step].copy_(self._seeds_dev)
+                else:
+                    with torch.no_grad():
+                        value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step), st.masks[step])
+                        log_prob = log_dist.gather(-1, action) if self.is_discrete_actions else log_dist
+                    st.insert_policy(hxs, action, log_prob, log_dist, value, self._seeds_dev if track_seeds else None)
+            last = step >= num_steps - 1
+            venv.step_env_pair_device(sts[0].actions[step].view(-1), sts[1].actions[step].view(-1), sts[0].step_out(step),
+                                      sts[1].step_out(step), last_step=last and sts[0].use_proper_time_limits)
+            for st in sts:
+                if last and not st.use_proper_time_limits:
+                    st.masks[step + 1].zero_()                          # done forced on the last step (:530)
+                if args.clip_reward:
+                    st.rewards[step].clamp_(-args.clip_reward, args.clip_reward)
+                st.advance()
+
     def agent_rollout(self, agent, num_steps, update=False, is_env=False, level_replay=False, level_sampler=None,
-                      update_level_sampler=False, discard_grad=False, edit_level=False, num_edits=0, fixed_seeds=None):
+                      update_level_sampler=False, discard_grad=False, edit_level=False, num_edits=0, fixed_seeds=None,
+                      rollout_done=False):
+        """rollout_done: the storage was already filled by `_paired_student_rollouts`; only the bookkeeping runs."""
         args = self.args
         B = args.num_processes
         if is_env:
@@ -493,7 +556,8 @@ class AdversarialRunner:
             self._flush_updates()
         if level_sampler and level_replay:
             rollout_info["solved_idx"] = np.zeros(B, dtype=bool)
-        self._student_rollout(agent, num_steps, level_replay, level_sampler, rollout_info)
+        if not rollout_done:
+            self._student_rollout(agent, num_steps, level_replay, level_sampler, rollout_info)
         stats = self._rollout_return_stats(agent.storage)
         rollout_info.update(stats)
         self.total_episodes_collected += stats["total_episodes"]
@@ -606,9 +670,17 @@ class AdversarialRunner:
                                       is_env=True, level_replay=level_replay,
                                       level_sampler=self._get_level_sampler("agent")[0], update_level_sampler=False)
         level_sampler, updateable = self._get_level_sampler("agent")
+        # plain PAIRED update: both students' rollouts in lock-step on two copies of the levels, then each one's bookkeeping
+        paired = bool(self.is_paired and not level_replay and self.pair_rollouts and self.is_discrete_actions
+                      and agent.storage.use_proper_time_limits == adversary_agent.storage.use_proper_time_limits)
+        if paired:
+            if any(a is ag for ag in (agent, adversary_agent) for a, _, _ in self._pending_updates):
+                self._flush_updates()
+            self._paired_student_rollouts((agent, adversary_agent), self.agent_rollout_steps, track_seeds=bool(self.level_samplers))
         agent_info = self.agent_rollout(agent=agent, num_steps=self.agent_rollout_steps, update=self.is_training,
                                         level_replay=level_replay, level_sampler=level_sampler,
-                                        update_level_sampler=updateable, discard_grad=student_discard_grad)
+                                        update_level_sampler=updateable, discard_grad=student_discard_grad,
+                                        rollout_done=paired)
         if level_replay and self.is_paired and (args.protagonist_plr == args.antagonist_plr):
             self.agent_rollout(agent=adversary_env, num_steps=self.adversary_env_rollout_steps, update=False,
                                is_env=True, level_replay=level_replay,
@@ -619,7 +691,7 @@ class AdversarialRunner:
             adversary_agent_info = self.agent_rollout(agent=adversary_agent, num_steps=self.agent_rollout_steps,
                                                       update=self.is_training, level_replay=level_replay,
                                                       level_sampler=level_sampler, update_level_sampler=updateable,
-                                                      discard_grad=student_discard_grad)
+                                                      discard_grad=student_discard_grad, rollout_done=paired)
 
         edit_level = self._should_edit_level() and level_replay
         if level_replay:

@@ -39,8 +39,12 @@ class HipAdversarialVecEnv:
         self.device = torch.device(device)
         self.env_index_base = int(env_index_base)
         cfg = self.proto.engine_config()
+        # two replicas of the batch in one allocation: PAIRED's protagonist and antagonist play the teacher's levels in
+        # independent rollouts (adversarial_runner.py:709-733); the second copy lets both advance in ONE launch per step
         self.engine = dcd_hip.MultiGridEngine(self.num_envs, device=device, engine_seed=int(engine_seed) & 0xFFFFFFFF,
-                                              env_index_base=self.env_index_base, **cfg)
+                                              env_index_base=self.env_index_base,
+                                              replicas=2 if cfg["size"] <= 15 else 1, **cfg)
+        self._twin = None
         p = self.proto
         V, S = p.agent_view_size, p.size
         self.action_space = p.action_space
@@ -103,6 +107,23 @@ class HipAdversarialVecEnv:
         """actions: int64 CUDA tensor [B]; out: dict for MultiGridEngine.step (tensors may be storage slices)."""
         flags = (STEP_RESET_RANDOM if reset_random else 0) | (STEP_LAST if last_step else 0)
         return self.engine.step(actions, flags, out)
+
+    @property
+    def twin(self):
+        """The second replica of the batch (dcd_mg_replica): the antagonist's copy of the levels."""
+        if self._twin is None:
+            self._twin = self.engine.replica(1)
+        return self._twin
+
+    def clone_to_twin(self):
+        self.twin.clone_levels(self.engine)
+
+    def reset_agent_twin_device(self, out):
+        return self.twin.reset_agent(out)
+
+    def step_env_pair_device(self, actions, twin_actions, out, twin_out, last_step=False):
+        """One launch for both copies (dcd_mg_step_pair); no reset_random: PAIRED levels come from the teacher."""
+        return self.engine.step_pair(self.twin, actions, twin_actions, STEP_LAST if last_step else 0, out, twin_out)
 
     def step_adversary_device(self, actions, out):
         return self.engine.step_adversary(actions, out)

@@ -271,3 +271,63 @@ def test_concurrent_ppo_updates_match_in_order_updates(monkeypatch):
     for n in w0:
         for k in w0[n]:
             torch.testing.assert_close(w1[n][k], w0[n][k], rtol=0, atol=2e-3, msg=f"{n}.{k}")
+
+
+def _storage_tensors(st):
+    out = {k: v for k, v in vars(st).items() if isinstance(v, torch.Tensor)}
+    for name in ("obs", "truncated_obs"):
+        d = getattr(st, name)
+        if isinstance(d, dict):
+            out.update({f"{name}.{k}": v for k, v in d.items()})
+    return out
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_paired_lockstep_rollouts_equal_the_two_sequential_rollouts(monkeypatch, fused):
+    """DCD_PAIR_ROLLOUT: protagonist and antagonist advance in ONE env-step launch per step on two copies of the teacher's
+    levels.  Same seeds, first update, policy on the fused HIP path (per-agent Philox streams): every tensor of both
+    students' storages is bit-identical to the reference order (two rollouts one after the other on the same envs,
+    adversarial_runner.py:709-733)."""
+    monkeypatch.setenv("DCD_FUSED_ACT", fused)
+    monkeypatch.setenv("DCD_HIP_GRAPHS", "0")
+    got = {}
+    for pair in ("1", "0"):
+        monkeypatch.setenv("DCD_PAIR_ROLLOUT", pair)
+        args = make_args(ued_algo="paired", num_processes=96, num_steps=40)
+        runner, venv = build(args)
+        assert runner.pair_rollouts == (pair == "1")
+        torch.manual_seed(11)
+        runner.run()                                                 # the storages keep the rollouts of this first update
+        got[pair] = {name: {k: v.clone() for k, v in _storage_tensors(runner.agents[name].storage).items()}
+                     for name in ("agent", "adversary_agent", "adversary_env")}
+        venv.close()
+    assert torch.equal(got["1"]["adversary_env"]["actions"], got["0"]["adversary_env"]["actions"])      # the same levels
+    for name in ("agent", "adversary_agent"):
+        assert got["1"][name]["actions"].float().std() > 0
+        if fused == "0":
+            # the modules draw from the ONE global torch generator: lock-step interleaves the two students' draws, so the
+            # action streams differ from the sequential order (same distribution)
+            assert torch.isfinite(got["1"][name]["returns"]).all()
+            continue
+        for k, v in got["1"][name].items():
+            assert torch.equal(v, got["0"][name][k]), (name, k)
+
+
+def test_paired_lockstep_training_runs_with_graphs_and_plr(monkeypatch):
+    """The lock-step rollouts under HIP-graph replay and with level replay bookkeeping (REPAIRED-style: PLR + PAIRED,
+    pair rollouts on the non-replay updates, sequential ones on replay updates): stats stay finite, both students
+    learn, the buffer fills."""
+    monkeypatch.setenv("DCD_PAIR_ROLLOUT", "1")
+    args = make_args(ued_algo="paired", use_plr=True, level_replay_prob=0.5, level_replay_rho=0.1, level_replay_seed_buffer_size=200,
+                     level_replay_strategy="positive_value_loss", level_replay_score_transform="rank", staleness_coef=0.3,
+                     num_processes=64, num_steps=32, env_name="MultiGrid-MiniGoalLastAdversarial-v0")
+    runner, venv = build(args)
+    np.random.seed(1)
+    kinds = set()
+    for _ in range(8):
+        s = runner.run()
+        kinds.add(bool(runner.sampled_level_info["level_replay"]))
+        assert np.isfinite(s["agent_value_loss"]) and np.isfinite(s["adversary_value_loss"])
+    assert kinds == {True, False}
+    assert any(k[0] == "pair" for k in runner._graphs)
+    venv.close()
