@@ -273,13 +273,29 @@ class RolloutStorage:
         return self.recurrent_hidden_states[step]
 
     # ---- PPO minibatch generators (reference :400-517) ------------------------------------------
+    def predraw_permutations(self, n_epochs, recurrent):
+        """Draws the minibatch permutations of the next `n_epochs` PPO epochs NOW, on the calling thread, from the global
+        torch generator (the draws torch.randperm would make inside the generators, in the same order).  The runner calls
+        it for each queued update in program order before running the updates concurrently on host threads, so that a
+        fixed --seed gives the same minibatches whatever the thread scheduling."""
+        n = self.num_processes if recurrent else self.rewards.shape[0] * self.rewards.shape[1]
+        self._perms = [torch.randperm(n) for _ in range(n_epochs)]
+
+    def _next_perm(self, n):
+        perms = getattr(self, "_perms", None)
+        if perms:
+            p = perms.pop(0)
+            assert p.numel() == n
+            return p
+        return torch.randperm(n)
+
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):
         T, B = self.rewards.shape[:2]
         total = T * B
         if mini_batch_size is None:
             assert total >= num_mini_batch
             mini_batch_size = total // num_mini_batch
-        perm = torch.randperm(total)
+        perm = self._next_perm(total)
         for s in range(0, total, mini_batch_size):
             idx = perm[s:s + mini_batch_size].to(self.device)
             flat = lambda x: x.reshape(-1, *x.shape[2:])[idx]
@@ -297,7 +313,7 @@ class RolloutStorage:
             f"PPO requires the number of processes ({B}) to be greater than or equal to "
             f"the number of PPO mini batches ({num_mini_batch}).")
         per = B // num_mini_batch
-        perm = torch.randperm(B)                                     # same draw as the reference (:450)
+        perm = self._next_perm(B)                                    # same draw as the reference (:450)
         for s in range(0, B, per):
             idx = perm[s:s + per].to(self.device)
             N = idx.numel()

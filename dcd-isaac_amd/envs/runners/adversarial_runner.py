@@ -610,6 +610,8 @@ class AdversarialRunner:
                 one(*job)
             return
         import threading
+        for agent, _, _ in jobs:                  # minibatch permutations in program order, whatever the threads do later
+            agent.storage.predraw_permutations(agent.algo.ppo_epoch, agent.is_recurrent)
         main = torch.cuda.current_stream(self.device)
         errors = []
 

@@ -60,6 +60,29 @@ def test_train_cli_logs_evaluates_checkpoints_and_resumes(tmp_path):
     assert steps[-1] == 7168 and steps[4] == (saved + 1) * 1024       # continued from the checkpointed update count
 
 
+def test_train_cli_checkpoints_by_default_and_after_the_last_update(tmp_path):
+    """Reference semantics (train.py:118-125,190-202): saving is ON unless --disable_checkpoint (--checkpoint only means
+    'resume'); model.tar is written after the LAST update even off-interval; archives are keyed to
+    runner.<checkpoint_basis> (here student_grad_updates, as three shipped configs set it)."""
+    common = [sys.executable, "train.py", f"--log_dir={tmp_path}", "--env_name=MultiGrid-MiniGoalLastAdversarial-v0",
+              "--ued_algo=domain_randomization", "--use_plr=True", "--use_reset_random_dr=True", "--no_exploratory_grad_updates=True",
+              "--level_replay_strategy=positive_value_loss", "--level_replay_score_transform=rank", "--level_replay_prob=0.5",
+              "--level_replay_rho=0.1", "--level_replay_seed_buffer_size=100", "--num_processes=32", "--num_steps=32", "--ppo_epoch=1",
+              "--handle_timelimits=True", "--log_interval=2", "--test_interval=0", "--num_env_steps=7168",      # 7 updates
+              "--checkpoint_interval=100", "--archive_interval=2", "--checkpoint_basis=student_grad_updates"]
+    _run(common + ["--xpid=dflt"])
+    d = os.path.join(str(tmp_path), "dflt")
+    sd = torch.load(os.path.join(d, "model.tar"), map_location="cpu", weights_only=False)["runner_state_dict"]
+    assert sd["num_updates"] == 7                                     # the final model, although 7 % 100 != 0
+    rows = _rows(os.path.join(d, "logs.csv"))
+    assert [int(float(r["steps"])) // 1024 for r in rows] == [1, 3, 5, 7]          # every log_interval and the last update
+    grad_updates = sd["student_grad_updates"]
+    archives = sorted(int(f[len("model_"):-len(".tar")]) for f in os.listdir(d) if f.startswith("model_") and f.endswith(".tar"))
+    assert archives and all(a % 2 == 0 and a <= grad_updates for a in archives)     # numbered by student grad updates
+    _run(common + ["--xpid=off", "--disable_checkpoint=True"])
+    assert not os.path.exists(os.path.join(str(tmp_path), "off", "model.tar"))
+
+
 def test_train_cli_two_ranks_robust_plr(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr=127.0.0.1",
            "--master-port=29641", "train.py", "--xpid=ddp", f"--log_dir={tmp_path}",

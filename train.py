@@ -64,31 +64,54 @@ def main():
         names = [n for n in args.test_env_names.split(",") if n]
         try:
             evaluator = Evaluator(names, num_processes=args.test_num_processes, num_episodes=args.test_num_episodes, device=device)
-        except NotImplementedError as e:                  # e.g. a 21x21 maze
+        except NotImplementedError as e:                  # a family the engine does not serve (e.g. the 3-agent cluttered grid)
             print(f"evaluation disabled: {e}", flush=True)
-    if args.checkpoint and os.path.exists(ckpt):          # preemption resume (train.py:129-134)
+
+    def checkpoint(index=None):                            # train.py:118-125: always on unless --disable_checkpoint
+        if args.disable_checkpoint or rank != 0:
+            return
+        os.makedirs(os.path.dirname(ckpt), exist_ok=True)
+        safe_checkpoint({"runner_state_dict": runner.state_dict()}, ckpt, index=index, archive_interval=args.archive_interval)
+
+    last_logged_at_restart = -1
+    if args.checkpoint and os.path.exists(ckpt):           # --checkpoint only means "resume a preempted job" (train.py:129-134)
         runner.load_state_dict(torch.load(ckpt, map_location=device, weights_only=False)["runner_state_dict"])
-    last, t0 = runner.num_updates, timeit.default_timer()
+        if writer is not None:
+            last_logged_at_restart = writer.latest_tick()  # ticks are 0-indexed updates: rows already in logs.csv are not repeated
+    elif args.xpid_finetune and not os.path.exists(ckpt):  # first iteration of a fine-tuning run (train.py:135-141)
+        base = os.path.expandvars(os.path.expanduser(os.path.join(args.log_dir, args.xpid_finetune, f"{args.model_finetune}.tar")))
+        sd = torch.load(base, map_location=device, weights_only=False)["runner_state_dict"]
+        runner.agents["agent"].algo.actor_critic.load_state_dict(sd["agent_state_dict"]["agent"])
+        runner.agents["agent"].algo.optimizer.load_state_dict(sd["optimizer_state_dict"]["agent"])
+    idx_at_start = getattr(runner, args.checkpoint_basis)
+    t0 = timeit.default_timer()
     for j in range(runner.num_updates, num_updates):
         stats = D.reduce_stats(runner.run())
-        test_stats = {}
-        if evaluator is not None and (j % args.test_interval == 0 or j == num_updates - 1):
-            test_stats = evaluator.evaluate(runner.agents["agent"])
-        if rank == 0 and j % args.log_interval == 0:
-            torch.cuda.synchronize()
-            now = timeit.default_timer()
-            n = j + 1 - last
-            sps = n * args.num_processes * world * args.num_steps / (now - t0)       # train.py:184
-            last, t0 = j + 1, now
-            row = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else None)
-                   for k, v in stats.items() if not hasattr(v, "__len__")}
-            row.update(test_stats)
-            row.update(sps=sps)
-            writer.log(dict(row))
-            print(json.dumps(dict(row, update=j)), flush=True)
-        if rank == 0 and args.checkpoint and j > 0 and j % args.checkpoint_interval == 0:
-            os.makedirs(os.path.dirname(ckpt), exist_ok=True)
-            safe_checkpoint({"runner_state_dict": runner.state_dict()}, ckpt, index=j, archive_interval=args.archive_interval)
+        if runner.num_updates > last_logged_at_restart:    # train.py:165-166
+            if j % args.log_interval == 0 or j == num_updates - 1:
+                test_stats = {}
+                if evaluator is not None and (j % args.test_interval == 0 or j == num_updates - 1):
+                    test_stats = evaluator.evaluate(runner.agents["agent"])
+                if rank == 0:
+                    torch.cuda.synchronize()
+                    now = timeit.default_timer()
+                    n = 1 if j == 0 else args.log_interval                           # train.py:182-184
+                    sps = n * args.num_processes * world * args.num_steps / (now - t0)
+                    t0 = now
+                    row = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else None)
+                           for k, v in stats.items() if not hasattr(v, "__len__")}
+                    row.update(sps=sps)
+                    row.update(test_stats)                                           # sps column before the test stats
+                    writer.log(dict(row))
+                    print(json.dumps(dict(row, update=j)), flush=True)
+        # train.py:190-202: keyed to runner.<checkpoint_basis> (num_updates or student_grad_updates); model.tar at every
+        # checkpoint_interval and after the LAST update, numbered copies at every archive_interval
+        idx = getattr(runner, args.checkpoint_basis)
+        if idx != idx_at_start:                            # (the reference compares with the value before the loop, :158,190-192)
+            if j == num_updates - 1 or (runner.num_updates > 0 and idx % args.checkpoint_interval == 0):
+                checkpoint(idx)
+            elif runner.num_updates > 0 and args.archive_interval > 0 and idx % args.archive_interval == 0:
+                checkpoint(idx)
         if rank == 0 and args.screenshot_interval > 0 and j % args.screenshot_interval == 0:     # train.py:169-171,204-232
             shot_dir = os.path.join(os.path.dirname(ckpt), "screenshots")
             os.makedirs(shot_dir, exist_ok=True)
