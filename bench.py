@@ -182,6 +182,40 @@ class ScoreExchange:
         return counts
 
 
+def grad_exchange_leg(device, world, iters=10):
+    """The large collective of the sharded training job, timed beside the pass (never inside `value`): the
+    per-minibatch gradient all-reduce of one PAIRED update — teacher 22 502 732 fp32 (90 MB) + 2 students x 433 953 fp32
+    (1.7 MB) — issued as algos.ppo.PPO issues it: flat buffers cut into 24 MB buckets, asynchronous all-reduces, one wait."""
+    import torch.distributed as dist
+    from algos.ppo import PPO
+    per = PPO.BUCKET_BYTES // 4
+    sizes = [22502732 + 3, 433953 + 3, 433953 + 3]
+    bufs = [torch.ones(n, device=device) for n in sizes]
+
+    def once():
+        hs = []
+        for b in bufs:
+            for lo in range(0, b.numel(), per):
+                hs.append(dist.all_reduce(b[lo:lo + per], async_op=True))
+        for h in hs:
+            h.wait()
+        for b in bufs:
+            b.div_(world)
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    nbytes = 4 * sum(sizes)
+    return {"what": "gradient all-reduce of one PAIRED minibatch (teacher 90 MB + 2 x student 1.7 MB, 24 MB buckets, async)",
+            "ms": dt * 1e3, "bytes": nbytes, "algbw_GBs": nbytes / dt / 1e9,
+            "busbw_GBs": nbytes / dt / 1e9 * 2 * (world - 1) / world, "per_update": "x5 epochs per agent"}
+
+
 def cpu_baseline(B, T, budget_s):
     """The CPU oracle (scalar C port of the reference's env path) on this box's host cores, on a bounded
     sample of the same workload: teacher-built levels + 256-step student rollouts with the same Philox
@@ -417,6 +451,7 @@ def main():
         n_recs = [int(a["scorer"].n_recs.item()) for a in ps.agents]
         episodes = [int(a["n_eps"].sum().item()) for a in ps.agents]
         kernel_s = step_kernel_profile(ps) if rank == 0 else None
+        grad_leg = grad_exchange_leg(device, world) if (dist is not None and args.dist_backend == "nccl") else None
         sweep = sweep_large_b(device) if (args.sweep and rank == 0 and world == 1) else None
 
     if rank == 0:
@@ -445,6 +480,8 @@ def main():
         }
         if sweep is not None:
             line["roofline_large_b"] = sweep
+        if grad_leg is not None:
+            line["grad_exchange"] = grad_leg
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(B, T, args.cpu_seconds)
             line["cpu_baseline_py_subproc"] = py_base

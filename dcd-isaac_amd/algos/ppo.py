@@ -58,19 +58,81 @@ class PPO:
         var = (s[1] - n * mean * mean) / (n - 1)
         return (adv - mean.float()) / (var.clamp_min(0).sqrt().float() + 1e-5)
 
-    def _sync_gradients(self):
-        """One bucketed all-reduce of the flattened gradient (1.7 MB student / 90 MB teacher)."""
-        if self.world_size == 1:
-            return
-        params = [p for p in self.actor_critic.parameters() if p.grad is not None]
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
-        self._all_reduce(flat)
-        flat /= self.world_size
-        off = 0
-        for p in params:
+    # ---- gradient exchange (no counterpart in the reference: one process there) ------------------------------------
+    # Every parameter's .grad is a VIEW into one persistent flat buffer (no cat / copy-back per minibatch: two passes over
+    # the 90 MB teacher gradient saved).  The buffer is cut into buckets of <= BUCKET_BYTES; a bucket's all-reduce is
+    # launched ASYNCHRONOUSLY from a post-accumulate-grad hook as soon as the backward pass has produced every gradient
+    # that lies in it (RCCL runs it on its own stream, overlapping the rest of the backward), and the three loss
+    # statistics of the minibatch ride in the tail of the buffer — one exchange per minibatch, nothing else.
+    BUCKET_BYTES = 24 << 20                       # teacher: 90 MB -> 4 buckets (its LSTM input weight alone is 89 MB)
+
+    def _setup_flat_grads(self):
+        params = [p for p in self.actor_critic.parameters() if p.requires_grad]
+        # reverse order: the backward pass reaches the heads first, the conv last -> buckets complete front to back
+        order = list(reversed(params))
+        total = sum(p.numel() for p in order)
+        flat = torch.zeros(total + 3, dtype=order[0].dtype, device=order[0].device)      # + value / action loss, entropy
+        off, spans = 0, []
+        for p in order:
             n = p.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            p.grad = flat[off:off + n].view_as(p)
+            spans.append((off, off + n))
             off += n
+        per = max(1, self.BUCKET_BYTES // flat.element_size())
+        nb = max(1, (total + per - 1) // per)
+        bounds = [(b * per, min((b + 1) * per, total)) for b in range(nb)]
+        bounds[-1] = (bounds[-1][0], total + 3)                                          # the statistics travel with the last bucket
+        need = [sum(1 for (a, e) in spans if a < hi and e > lo) for (lo, hi) in bounds]
+        touching = [[b for b, (lo, hi) in enumerate(bounds) if a < hi and e > lo] for (a, e) in spans]
+        self._flat_grad, self._flat_params, self._bucket_bounds = flat, order, bounds
+        self._bucket_need, self._bucket_of = need, touching
+        self._bucket_left, self._handles, self._launched = list(need), [], [False] * nb
+        if self.world_size > 1:
+            for i, p in enumerate(order):
+                p.register_post_accumulate_grad_hook(lambda _p, i=i: self._grad_ready(i))
+
+    def _launch_bucket(self, b):
+        import torch.distributed as dist
+        lo, hi = self._bucket_bounds[b]
+        self._launched[b] = True
+        self._handles.append(dist.all_reduce(self._flat_grad[lo:hi], group=self.process_group, async_op=True))
+
+    def _grad_ready(self, i):
+        """Post-accumulate hook of parameter i (same order on every rank: same graph): a bucket goes out once its last
+        gradient is in.  The final bucket also carries the loss statistics and is launched by `_sync_gradients`."""
+        last = len(self._bucket_bounds) - 1
+        for b in self._bucket_of[i]:
+            self._bucket_left[b] -= 1
+            if self._bucket_left[b] == 0 and b != last:
+                self._launch_bucket(b)
+
+    def _zero_grad(self):
+        if self._flat_grad is None:
+            self._setup_flat_grads()
+        off = 0
+        for p in self._flat_params:                                   # re-attach a .grad someone set to None / replaced
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self._flat_grad[off:off + n].data_ptr():
+                p.grad = self._flat_grad[off:off + n].view_as(p)
+            off += n
+        self._flat_grad.zero_()
+        self._bucket_left, self._handles = list(self._bucket_need), []
+        self._launched = [False] * len(self._bucket_bounds)
+
+    def _sync_gradients(self, stats):
+        """Launches what the hooks did not (the final bucket with the statistics in its tail; buckets whose parameters
+        received no gradient), waits, averages.  Returns the job-wide means of `stats` (value loss, action loss,
+        entropy) — they cost no collective of their own."""
+        if self.world_size == 1:
+            return stats
+        self._flat_grad[-3:].copy_(stats)
+        for b in range(len(self._bucket_bounds)):
+            if not self._launched[b]:
+                self._launch_bucket(b)
+        for h in self._handles:
+            h.wait()
+        self._flat_grad /= self.world_size
+        return self._flat_grad[-3:].clone()
 
     def _grad_norm(self):
         total = 0.0
@@ -99,20 +161,16 @@ class PPO:
                     value_loss = 0.5 * torch.max((values - return_b).pow(2), (clipped - return_b).pow(2)).mean()
                 else:
                     value_loss = F.smooth_l1_loss(values, return_b)
-                self.optimizer.zero_grad()
+                self._zero_grad()
                 loss = value_loss * self.value_loss_coef + action_loss - dist_entropy * self.entropy_coef
                 loss.backward()
-                self._sync_gradients()
+                stats = self._sync_gradients(torch.stack([value_loss.detach(), action_loss.detach(), dist_entropy.detach()]))
                 if self.log_grad_norm:
                     grad_norms.append(self._grad_norm())
                 if self.max_grad_norm is not None and self.max_grad_norm > 0:
                     nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
                 if not discard_grad:
                     self.optimizer.step()
-                stats = torch.stack([value_loss.detach(), action_loss.detach(), dist_entropy.detach()])
-                if self.world_size > 1:
-                    self._all_reduce(stats)
-                    stats /= self.world_size
                 v, a, e = stats.tolist()
                 value_loss_epoch += v
                 action_loss_epoch += a

@@ -256,13 +256,11 @@ class AdversarialRunner:
         return [v for v in self.level_samplers.values() if v is not None]
 
     def _from_rank0(self, value):
-        """Host-side random decisions must agree on every rank: rank 0's draw wins."""
+        """Host-side random decisions must agree on every rank: rank 0's draw wins (one small tensor broadcast)."""
         if self.world_size == 1:
             return value
-        import torch.distributed as dist
-        box = [value]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(self.process_group, 0), group=self.process_group)
-        return box[0]
+        from util import distributed as D
+        return bool(D.broadcast_ints([int(bool(value))], 1, group=self.process_group, device=self.device)[0])
 
     def _should_edit_level(self):
         return bool(self._from_rank0(bool(self.use_editor and np.random.rand() < self.edit_prob)))

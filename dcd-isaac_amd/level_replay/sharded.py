@@ -89,12 +89,19 @@ class ShardedLevelSampler:
         return _broadcast_object(fn(self.sampler) if self.rank == 0 else None, self.group)
 
     def sample_replay_decision(self):
-        return bool(self._from_root(lambda s: s.sample_replay_decision()))
+        from util import distributed as D
+        d = int(bool(self.sampler.sample_replay_decision())) if self.rank == 0 else 0
+        return bool(D.broadcast_ints([d], 1, group=self.group)[0])
 
     def sample_replay_levels(self, n, update_staleness=True):
-        """n replay seeds for THIS rank; rank 0 draws sum(n) sequentially in global env order."""
-        counts = _all_gather_object(int(n), self.group)
-        seeds = self._from_root(lambda s: s.sample_replay_levels(sum(counts), update_staleness=update_staleness))
+        """n replay seeds for THIS rank; rank 0 draws sum(n) sequentially in global env order (the draws are sequential
+        by definition: each one ages the whole buffer, level_sampler.py:664-680).  Three small tensor collectives
+        (counts, seeds) — on the GPU path RCCL, no pickling."""
+        from util import distributed as D
+        counts = [c[0] for c in D.gather_int_lists([int(n)], group=self.group)]
+        total = sum(counts)
+        seeds = self.sampler.sample_replay_levels(total, update_staleness=update_staleness) if (self.rank == 0 and total) else []
+        seeds = D.broadcast_ints(seeds, total, group=self.group) if total else []
         off = sum(counts[:self.rank])
         return seeds[off:off + n]
 
@@ -131,14 +138,17 @@ class ShardedLevelSampler:
 
     # ---- all -> rank 0 ---------------------------------------------------------------------------
     def observe_external_unseen_sample(self, seeds, solvable=None):
-        parts = _all_gather_object(([int(s) for s in seeds], None if solvable is None else [bool(x) for x in solvable]),
-                                   self.group)
+        from util import distributed as D
+        # seed and solvable flag of every new level in one ragged int gather: 2*seed + solvable (-1: no flags given)
+        code = [2 * int(s) + (int(bool(x)) if solvable is not None else 0) for s, x in
+                zip(seeds, solvable if solvable is not None else [0] * len(seeds))]
+        parts = D.gather_int_lists([1 if solvable is not None else 0] + code, group=self.group)
         if self.rank == 0:
-            all_seeds = [s for p in parts for s in p[0]]
-            all_solv = None if parts[0][1] is None else [x for p in parts for x in p[1]]
+            all_seeds = [c >> 1 for p in parts for c in p[1:]]
+            all_solv = [bool(c & 1) for p in parts for c in p[1:]] if parts[0][0] else None
             self.sampler.observe_external_unseen_sample(all_seeds, all_solv)
 
-    def score_rollouts(self, rollouts):
+    def score_rollouts(self, rollouts, to_host=True):
         from dcd_hip import scans
         T, B = rollouts.action_log_dist.shape[:2]
         if self._scorer is None or (self._scorer.T, self._scorer.B) != (T, B) or self._scorer.device != rollouts.device:
@@ -146,18 +156,28 @@ class ShardedLevelSampler:
         self._scorer.launch(rollouts.returns, rollouts.value_preds, rollouts.rewards, rollouts.masks,
                             rollouts.cliffhanger_masks, rollouts.level_seeds, rollouts.action_log_dist,
                             _GPU_STRATEGY[self.strategy], self.gamma)
-        return self._scorer.records()
+        return self._scorer.records() if to_host else None
 
     def update_with_rollouts(self, rollouts):
         if self.strategy in ("random", "off"):
             return
         if self.strategy not in _GPU_STRATEGY:
             raise ValueError(f"Unsupported strategy, {self.strategy}")
-        recs = self.score_rollouts(rollouts)
+        from util import distributed as D
+        self.score_rollouts(rollouts, to_host=False)
         values = None
         if self.strategy.startswith("grounded"):
             values = rollouts.value_preds[:, :, 0].float().cpu().numpy()
-        self.update_with_records(recs, values, device=rollouts.device)
+        # the records leave the scorer's device buffers in ONE fixed-capacity all-gather; only rank 0 reads them back
+        sc = self._scorer
+        counts, recv = D.gather_records_device(sc.recs, sc.n_recs, group=self.group, cap=4 * sc.B)
+        vals = _all_gather_object(values, self.group) if values is not None else [None] * self.world
+        if self.rank == 0:
+            from dcd_hip.scans import EPISODE_REC
+            body = recv[:, 1:].cpu().numpy()
+            for r, c in enumerate(counts):
+                part = body[r, :c * 8].copy().view(EPISODE_REC).reshape(c)
+                self.sampler.update_with_records(part, vals[r], actor_offset=r * self.local_actors)
 
     def update_with_records(self, recs, values=None, device="cpu"):
         """This rank's records (local actor indices) -> rank 0's sampler, consumed rank-major.  The records

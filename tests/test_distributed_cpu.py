@@ -30,6 +30,25 @@ def _setup(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
+def _eight_envs(g):
+    """The golden 4-env rollout widened to 8 distinct envs: columns 4..7 are columns 3,0,1,2 with other returns / values."""
+    out = {}
+    for k in g.files:
+        a = g[k]
+        if k in ("img", "direction", "masks", "rewards", "hidden", "act_actions", "act_values", "action_log_probs", "returns"):
+            b = np.roll(a, 1, axis=1)
+            if k in ("returns", "act_values", "rewards"):
+                b = (b * 0.5 + 0.1).astype(a.dtype)
+            a = np.concatenate([a, b], axis=1)
+        elif k == "next_value":
+            a = np.concatenate([a, np.roll(a, 1, axis=0) * 0.5], axis=0)
+        out[k] = a
+
+    class _G(dict):
+        files = list(out)
+    return _G(out)
+
+
 def _build(g, envs, process_group):
     from algos import ACAgent, PPO, RolloutStorage
     from envs import spaces
@@ -61,6 +80,41 @@ def _ppo_worker(rank, world, port, out_path):
         torch.save({"sd": net.state_dict(), "losses": (vl, al, ent)}, out_path)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _ppo8_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    from algos import PPO
+    PPO.BUCKET_BYTES = 256 << 10                                   # the 1.7 MB student gradient in 7 buckets
+    g = _eight_envs(np.load(os.path.join(G, "ppo.npz")))
+    agent, net = _build(g, [rank], dist.group.WORLD)
+    torch.manual_seed(2)
+    vl, al, ent, _ = agent.update()
+    assert len(agent.algo._bucket_bounds) >= 6 and all(agent.algo._launched)
+    if rank == 0:
+        torch.save({"sd": net.state_dict(), "losses": (vl, al, ent)}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ppo_eight_ranks_bucketed_exchange_equals_single_process():
+    """8 ranks x 1 env, gradients in a flat buffer exchanged as 7 asynchronous bucket all-reduces launched from the
+    backward hooks, loss statistics in the last bucket's tail == one process with the 8 envs."""
+    for p in (ROOT, os.path.join(ROOT, "dcd-isaac_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    g = _eight_envs(np.load(os.path.join(G, "ppo.npz")))
+    agent, net = _build(g, list(range(8)), None)
+    torch.manual_seed(2)
+    ref_losses = agent.update()[:3]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "r0.pt")
+        mp.spawn(_ppo8_worker, args=(8, 29543, out), nprocs=8, join=True)
+        got = torch.load(out, weights_only=False)
+    np.testing.assert_allclose(got["losses"], ref_losses, rtol=1e-4, atol=1e-7)
+    for k, v in net.state_dict().items():
+        np.testing.assert_allclose(got["sd"][k].numpy(), v.numpy(), rtol=0, atol=3e-6, err_msg=k)
 
 
 def test_sharded_ppo_equals_single_process():

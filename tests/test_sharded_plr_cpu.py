@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: level replay with the env batch sharded over ranks.
+"""CPU, world_size 2 and 8 over gloo: level replay with the env batch sharded over ranks.
 
 One LevelSampler on rank 0 fed by all-gathered episode records + a replicated LevelStore must behave
 exactly like the reference's single process holding all world x B envs: same replay decisions, same seeds
@@ -23,7 +23,7 @@ for p in (ROOT, os.path.join(ROOT, "dcd-isaac_amd")):
 
 REC = np.dtype([("actor", "<i4"), ("seed", "<i4"), ("start_t", "<i4"), ("num_steps", "<i4"), ("mean_score", "<f4"),
                 ("max_score", "<f4"), ("reward_sum", "<f4"), ("flags", "<i4")])
-B_LOCAL, WORLD, UPDATES = 4, 2, 8
+B_LOCAL, UPDATES = 4, 8
 
 
 class _Space:
@@ -101,17 +101,21 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_level_replay_equals_single_process():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("WORLD", [2, 8])
+def test_sharded_level_replay_equals_single_process(WORLD):
     from level_replay import LevelSampler, LevelStore
     np.random.seed(7)
     ref_sampler, ref_store = LevelSampler(**_plr_args(B_LOCAL * WORLD)), LevelStore()
     ref_log = _drive(ref_sampler, ref_store, 0, B_LOCAL * WORLD, ref_sampler.update_with_records)
     assert any(r[0] for r in ref_log) and not all(r[0] for r in ref_log)       # both branches exercised
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(WORLD, 29541, d), nprocs=WORLD, join=True)
+        mp.spawn(_worker, args=(WORLD, 29541 + WORLD, d), nprocs=WORLD, join=True)
         got = [pickle.load(open(os.path.join(d, f"r{r}.pkl"), "rb")) for r in range(WORLD)]
     for u, ref in enumerate(ref_log):
-        seeds = got[0]["log"][u][1] + got[1]["log"][u][1]
+        seeds = [x for g in got for x in g["log"][u][1]]
         assert [g["log"][u][0] for g in got] == [ref[0]] * WORLD, u
         assert seeds == ref[1], u
         for g in got:
