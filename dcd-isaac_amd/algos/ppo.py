@@ -143,7 +143,8 @@ class PPO:
 
     # ---- update -------------------------------------------------------------------------------
     def update(self, rollouts, discard_grad=False):
-        advantages = rollouts.returns[:-1] - rollouts.value_preds[:-1]
+        value_preds = rollouts.denorm_value_preds if rollouts.use_popart else rollouts.value_preds      # ppo.py:62-65
+        advantages = rollouts.returns[:-1] - value_preds[:-1]
         advantages = self._normalize_advantages(advantages)
         value_loss_epoch = action_loss_epoch = dist_entropy_epoch = 0.0
         grad_norms = []
@@ -156,6 +157,9 @@ class PPO:
                 surr1 = ratio * adv_b
                 surr2 = torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_b
                 action_loss = -torch.min(surr1, surr2).mean()
+                if rollouts.use_popart:                              # ppo.py:102-104: targets in PopArt's normalised space
+                    self.actor_critic.popart.update(return_b)
+                    return_b = self.actor_critic.popart.normalize(return_b)
                 if self.clip_value_loss:
                     clipped = value_preds_b + (values - value_preds_b).clamp(-self.clip_param, self.clip_param)
                     value_loss = 0.5 * torch.max((values - return_b).pow(2), (clipped - return_b).pow(2)).mean()

@@ -30,8 +30,6 @@ class RolloutStorage:
     def __init__(self, model, num_steps, num_processes, observation_space, action_space,
                  recurrent_hidden_state_size, recurrent_arch="rnn", use_proper_time_limits=False,
                  use_popart=False, device="cpu"):
-        if use_popart:
-            raise NotImplementedError("PopArt is off in every MultiGrid config (SURVEY §2 #15); not supported")
         self.device = torch.device(device)
         self.model = model
         self.num_steps, self.num_processes = num_steps, num_processes
@@ -39,7 +37,7 @@ class RolloutStorage:
         self.recurrent_hidden_state_size = recurrent_hidden_state_size
         self.is_lstm = recurrent_arch == "lstm"
         self.use_proper_time_limits = use_proper_time_limits
-        self.use_popart = False
+        self.use_popart = bool(use_popart)      # value_preds are normalised; model.popart denormalises them (:240-247)
         T, B, d = num_steps, num_processes, self.device
         z = lambda *s, **kw: torch.zeros(*s, device=d, **kw)
         self.is_dict_obs = isinstance(observation_space, dict)
@@ -199,14 +197,18 @@ class RolloutStorage:
 
     def _value_source(self, next_value):
         self.value_preds[-1] = next_value
-        if self.use_proper_time_limits:
-            return self._compute_truncated_value_preds()
-        return self.value_preds
+        v = self._compute_truncated_value_preds() if self.use_proper_time_limits else self.value_preds
+        if self.use_popart:                          # storage.py:247-249,269-270: every value prediction denormalised
+            self.denorm_value_preds = self.model.popart.denormalize(v).contiguous()
+        return v
 
     def compute_gae_returns(self, returns_buffer, next_value, gamma, gae_lambda):
-        scans.gae_returns(self.rewards, self._value_source(next_value), self.masks, returns_buffer, gamma, gae_lambda)
+        v = self._value_source(next_value)
+        scans.gae_returns(self.rewards, self.denorm_value_preds if self.use_popart else v, self.masks, returns_buffer, gamma, gae_lambda)
 
     def compute_discounted_returns(self, returns_buffer, next_value, gamma):
+        # the reference seeds the scan with the NORMALISED last value even under PopArt (:266-272: denorm_value_preds is
+        # computed but returns[-1] = value_preds[-1]); kept
         scans.discounted_returns(self.rewards, self._value_source(next_value), self.masks, returns_buffer, gamma)
 
     def compute_returns(self, next_value, use_gae, gamma, gae_lambda):
@@ -217,7 +219,8 @@ class RolloutStorage:
 
     def get_batched_value_loss(self, signed=False, positive_only=False, power=1, clipped=True, batched=True):
         mode = 1 if signed else (2 if positive_only else 0)
-        out = scans.batched_value_loss(self.returns, self.value_preds, mode, int(power), clipped)
+        v = self.denorm_value_preds if self.use_popart else self.value_preds      # :301-306
+        out = scans.batched_value_loss(self.returns, v, mode, int(power), clipped)
         return out if batched else out.mean().item()
 
     # ---- action trajectories ----------------------------------------------------------------

@@ -529,6 +529,47 @@ __global__ void env_return_kernel(const float* __restrict__ am, const float* __r
 #define HIP_OK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return dcd::fail("%s: %s", #x, hipGetErrorString(_e)); } while (0)
 static inline int nblk(int n) { return (n + SCAN_BLOCK - 1) / SCAN_BLOCK; }
 
+// ---- VecNormalize(ret=True).step_wait (envs/wrappers/vec_normalize.py:37-45) --------------------------------------------------
+// ret = ret*gamma + rews; ret_rms.update(ret); rews = clip(rews / sqrt(ret_rms.var + eps), -cliprew, cliprew); ret[news] = 0.
+// fp64 throughout like the numpy statement (rews promoted from fp32); ret_rms is baselines' RunningMeanStd: batch mean and
+// population variance merged into (mean, var, count) by the parallel-variance formula.  One workgroup: the batch moments are
+// two deterministic tree reductions (numpy sums pairwise: the last bits of the moments may differ, tolerance in the tests).
+__global__ void __launch_bounds__(1024) return_normalize_kernel(float* __restrict__ rew, const uint8_t* __restrict__ done, double* __restrict__ ret,
+                                                                double* __restrict__ rms, double gamma, double eps, double clip, int B) {
+  __shared__ double red[1024];
+  __shared__ double bcast;
+  const int tid = threadIdx.x;
+  auto reduce = [&](double v) {
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+  };
+  double a = 0.0;
+  for (int i = tid; i < B; i += 1024) { const double r = ret[i] * gamma + (double)rew[i]; ret[i] = r; a += r; }
+  const double bmean = reduce(a) / (double)B;
+  double q = 0.0;
+  for (int i = tid; i < B; i += 1024) { const double d = ret[i] - bmean; q += d * d; }
+  const double bvar = reduce(q) / (double)B;
+  if (tid == 0) {                                   // RunningMeanStd.update_from_moments
+    const double mean = rms[0], var = rms[1], count = rms[2], bc = (double)B;
+    const double delta = bmean - mean, tot = count + bc;
+    const double m2 = var * count + bvar * bc + delta * delta * count * bc / tot;
+    rms[0] = mean + delta * bc / tot; rms[1] = m2 / tot; rms[2] = tot;
+    bcast = sqrt(m2 / tot + eps);
+  }
+  __syncthreads();
+  const double sd = bcast;
+  for (int i = tid; i < B; i += 1024) {
+    double r = (double)rew[i] / sd;
+    r = r < -clip ? -clip : (r > clip ? clip : r);
+    rew[i] = (float)r;
+    if (done[i]) ret[i] = 0.0;
+  }
+}
+
 extern "C" {
 
 int dcd_gae_returns(const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T, int32_t B,
@@ -598,6 +639,14 @@ int dcd_episode_scores(const float* returns, const float* value_preds, const flo
     DCD_SCORE_CASE(5) DCD_SCORE_CASE(6) DCD_SCORE_CASE(7) DCD_SCORE_CASE(8)
 #undef DCD_SCORE_CASE
   }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int dcd_return_normalize(float* rewards, const uint8_t* done, double* ret, double* rms, double gamma, double epsilon, double cliprew,
+                         int32_t B, void* stream) {
+  if (!rewards || !done || !ret || !rms || B <= 0) return dcd::fail("dcd_return_normalize: bad arguments");
+  hipLaunchKernelGGL(return_normalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rewards, done, ret, rms, gamma, epsilon, cliprew, B);
   HIP_OK(hipGetLastError());
   return 0;
 }

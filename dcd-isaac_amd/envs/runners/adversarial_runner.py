@@ -672,6 +672,7 @@ class AdversarialRunner:
         level_sampler, updateable = self._get_level_sampler("agent")
         # plain PAIRED update: both students' rollouts in lock-step on two copies of the levels, then each one's bookkeeping
         paired = bool(self.is_paired and not level_replay and self.pair_rollouts and self.is_discrete_actions
+                      and not getattr(self.venv, "normalize_returns", False)     # one running-return state per venv: keep the order
                       and agent.storage.use_proper_time_limits == adversary_agent.storage.use_proper_time_limits)
         if paired:
             if any(a is ag for ag in (agent, adversary_agent) for a, _, _ in self._pending_updates):

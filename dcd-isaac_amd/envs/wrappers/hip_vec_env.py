@@ -28,7 +28,8 @@ from envs import spaces
 
 
 class HipAdversarialVecEnv:
-    def __init__(self, env_fns, adversary=True, is_eval=False, device="cuda:0", env_index_base=0, engine_seed=0):
+    def __init__(self, env_fns, adversary=True, is_eval=False, device="cuda:0", env_index_base=0, engine_seed=0,
+                 normalize_returns=False, ret_gamma=0.99, cliprew=10.0, ret_epsilon=1e-8):
         if len(env_fns) == 0:
             raise ValueError("need at least one env_fn")
         self.closed = False
@@ -45,6 +46,13 @@ class HipAdversarialVecEnv:
                                               env_index_base=self.env_index_base,
                                               replicas=2 if cfg["size"] <= 15 else 1, **cfg)
         self._twin = None
+        # VecNormalize(ob=False, ret=args.normalize_returns) of the reference's stack (util/__init__.py:193; defaults of
+        # vec_normalize.py:24): running discounted returns + their RunningMeanStd live on the device, one kernel per step
+        self.normalize_returns = bool(normalize_returns)
+        self._ret_cfg = (float(ret_gamma), float(ret_epsilon), float(cliprew))
+        if self.normalize_returns:
+            self._ret = torch.zeros(self.num_envs, dtype=torch.float64, device=self.device)
+            self.ret_rms = torch.tensor([0.0, 1.0, 1e-4], dtype=torch.float64, device=self.device)   # mean, var, count
         p = self.proto
         V, S = p.agent_view_size, p.size
         self.action_space = p.action_space
@@ -106,7 +114,22 @@ class HipAdversarialVecEnv:
     def step_env_device(self, actions, out, reset_random=False, last_step=False):
         """actions: int64 CUDA tensor [B]; out: dict for MultiGridEngine.step (tensors may be storage slices)."""
         flags = (STEP_RESET_RANDOM if reset_random else 0) | (STEP_LAST if last_step else 0)
-        return self.engine.step(actions, flags, out)
+        out = self.engine.step(actions, flags, out)
+        if self.normalize_returns:
+            self._normalize(out["reward"], out["done"])
+        return out
+
+    def _normalize(self, reward, done):
+        import ctypes as C
+        from dcd_hip import check, lib, ptr, stream_ptr
+        g, eps, clip = self._ret_cfg
+        check(lib().dcd_return_normalize(ptr(reward, torch.float32, self.num_envs, "reward"), ptr(done, torch.uint8, self.num_envs, "done"),
+                                         ptr(self._ret, torch.float64), ptr(self.ret_rms, torch.float64), C.c_double(g),
+                                         C.c_double(eps), C.c_double(clip), C.c_int32(self.num_envs), stream_ptr()))
+
+    def _reset_returns(self):
+        if self.normalize_returns:                                    # vec_normalize.py:56-70: every reset* zeroes the running returns
+            self._ret.zero_()
 
     @property
     def twin(self):
@@ -129,12 +152,15 @@ class HipAdversarialVecEnv:
         return self.engine.step_adversary(actions, out)
 
     def reset_device(self, out):
+        self._reset_returns()
         return self.engine.reset(out)
 
     def reset_agent_device(self, out):
+        self._reset_returns()
         return self.engine.reset_agent(out)
 
     def reset_random_device(self, out):
+        self._reset_returns()
         return self.engine.reset_random(out)
 
     # ------------------------------------------------------------------ reference-compatible level
@@ -142,6 +168,7 @@ class HipAdversarialVecEnv:
         """Adversarial families: AdversarialEnv.reset (teacher obs).  Fixed-level families (eval mazes):
         MultiGridEnv.reset — reload the level, student obs (eval.py:266)."""
         self._assert_not_closed()
+        self._reset_returns()
         if self.is_fixed_level:
             if self.is_procedural:
                 self._fixed_levels.copy_(torch.from_numpy(np.stack([d.level_encoding() for d in self._descs])))
@@ -167,12 +194,14 @@ class HipAdversarialVecEnv:
 
     def reset_agent(self):
         self._assert_not_closed()
+        self._reset_returns()
         obs = self._student_dict(self.engine.reset_agent(self._student_out()))
         self.raise_errors()
         return obs
 
     def reset_random(self):
         self._assert_not_closed()
+        self._reset_returns()
         return self._student_dict(self.engine.reset_random(self._student_out()))
 
     def _levels_to_device(self, levels):
@@ -241,7 +270,7 @@ class HipAdversarialVecEnv:
         self._assert_not_closed()
         if self._step_out is None:
             self._step_out = self.engine.step_buffers(u8=False)
-        out = self.engine.step(self._actions(actions), STEP_RESET_RANDOM if reset_random else 0, self._step_out)
+        out = self.step_env_device(self._actions(actions), self._step_out, reset_random=reset_random)
         info = out["info"].cpu().numpy()                         # synchronises
         self.raise_errors()
         done = out["done"].cpu().numpy().astype(bool)

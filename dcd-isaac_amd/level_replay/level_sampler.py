@@ -29,6 +29,11 @@ _VALUE_STRATEGIES = ("gae", "value_l1", "signed_value_loss", "positive_value_los
                      "grounded_positive_value_loss", "one_step_td_error", "alt_advantage_abs", "tscl_window")
 
 
+def _scoring_values(rollouts):
+    """Value predictions the score functions compare returns with: denormalised under PopArt (level_sampler.py:520-525)."""
+    return rollouts.denorm_value_preds if getattr(rollouts, "use_popart", False) else rollouts.value_preds
+
+
 _NATIVE_DRAWS = None
 
 
@@ -267,7 +272,7 @@ class LevelSampler:
         recs = self.score_rollouts(rollouts)
         values = None
         if self.grounded_values is not None:
-            values = rollouts.value_preds[:, :, 0].float().cpu().numpy()
+            values = _scoring_values(rollouts)[:, :, 0].float().cpu().numpy()
         self.update_with_records(recs, values)
 
     def score_rollouts(self, rollouts):
@@ -276,7 +281,7 @@ class LevelSampler:
         T, B = rollouts.action_log_dist.shape[:2]
         if self._scorer is None or (self._scorer.T, self._scorer.B) != (T, B) or self._scorer.device != rollouts.device:
             self._scorer = scans.EpisodeScorer(T, B, rollouts.device)
-        self._scorer.launch(rollouts.returns, rollouts.value_preds, rollouts.rewards, rollouts.masks,
+        self._scorer.launch(rollouts.returns, _scoring_values(rollouts), rollouts.rewards, rollouts.masks,
                             rollouts.cliffhanger_masks, rollouts.level_seeds, rollouts.action_log_dist,
                             _GPU_STRATEGY[self.strategy], self.gamma)
         return self._scorer.records()

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .level_sampler import LevelSampler, _GPU_STRATEGY
+from .level_sampler import LevelSampler, _GPU_STRATEGY, _scoring_values
 from .level_store import LevelStore
 
 
@@ -153,7 +153,7 @@ class ShardedLevelSampler:
         T, B = rollouts.action_log_dist.shape[:2]
         if self._scorer is None or (self._scorer.T, self._scorer.B) != (T, B) or self._scorer.device != rollouts.device:
             self._scorer = scans.EpisodeScorer(T, B, rollouts.device)
-        self._scorer.launch(rollouts.returns, rollouts.value_preds, rollouts.rewards, rollouts.masks,
+        self._scorer.launch(rollouts.returns, _scoring_values(rollouts), rollouts.rewards, rollouts.masks,
                             rollouts.cliffhanger_masks, rollouts.level_seeds, rollouts.action_log_dist,
                             _GPU_STRATEGY[self.strategy], self.gamma)
         return self._scorer.records() if to_host else None
@@ -167,7 +167,7 @@ class ShardedLevelSampler:
         self.score_rollouts(rollouts, to_host=False)
         values = None
         if self.strategy.startswith("grounded"):
-            values = rollouts.value_preds[:, :, 0].float().cpu().numpy()
+            values = _scoring_values(rollouts)[:, :, 0].float().cpu().numpy()
         # the records leave the scorer's device buffers in ONE fixed-capacity all-gather; only rank 0 reads them back
         sc = self._scorer
         counts, recv = D.gather_records_device(sc.recs, sc.n_recs, group=self.group, cap=4 * sc.B)

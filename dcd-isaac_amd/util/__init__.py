@@ -124,13 +124,12 @@ def _make_env(args):
 
 def create_parallel_env(args, adversary=True, device=None, env_index_base=0):
     """(venv, ued_venv) as util/__init__.py:184-220; the whole wrapper stack is one HipAdversarialVecEnv."""
-    if vars(args).get("normalize_returns", False):
-        raise NotImplementedError("VecNormalize(ret=True) is off in every MultiGrid config; not supported")
     if device is None:
         device = "cuda:0"
     make_fn = lambda: _make_env(args)
     venv = HipAdversarialVecEnv([make_fn] * args.num_processes, adversary=adversary, device=device,
-                                env_index_base=env_index_base, engine_seed=args.seed)
+                                env_index_base=env_index_base, engine_seed=args.seed,
+                                normalize_returns=bool(vars(args).get("normalize_returns", False)))
     if args.singleton_env:
         seeds = [args.seed] * args.num_processes
     else:

@@ -317,6 +317,26 @@ int dcd_rollout_return_stats(const float* ep_ret, const uint8_t* info, int32_t T
 int dcd_env_return(const float* agent_mean, const float* agent_max, const float* adv_mean,
                    const float* adv_max, float* out, int32_t B, int32_t mode, void* stream);
 
+/* ---- return normalisation (BASELINE configs 4-5 train with --normalize_returns) -------------------------------- */
+/* VecNormalize(ob=False, ret=True).step_wait (envs/wrappers/vec_normalize.py:37-45) on the batch's rewards, between the
+ * episode accounting (VecMonitor sees the raw rewards) and the preprocessing wrapper, as util/__init__.py:191-193 stacks
+ * them: ret = ret*gamma + rewards; ret_rms.update(ret); rewards = clip(rewards / sqrt(ret_rms.var + epsilon), +-cliprew);
+ * ret[done] = 0.  rewards float[B] in place; done uint8[B]; ret double[B] (the wrapper's running returns, zeroed by
+ * the caller on reset*); rms double[3] = (mean, var, count) of baselines' RunningMeanStd (initially 0, 1, 1e-4). */
+int dcd_return_normalize(float* rewards, const uint8_t* done, double* ret, double* rms, double gamma, double epsilon,
+                         double cliprew, int32_t B, void* stream);
+
+/* ---- Bézier track of a CarRacing level (BASELINE config 5) ------------------------------------------------------ */
+/* envs/box2d/bezier.py:get_bezier_curve (:56-82) for a batch of levels, as CarRacingBezier._create_track_bezier calls it
+ * (envs/box2d/car_racing_bezier.py:297-303: rad 0.2, edgy 0.2, numpoints 40): points double[B,max_points,2] (the first
+ * n_points[b] rows of level b are its control points, 2 <= n <= 64), sorted counter-clockwise about their centroid, tangent
+ * angles from the adjacent chords, one cubic segment per consecutive pair of the CLOSED polygon, numpoints samples each.
+ * xy double[B, max_points*numpoints, 2]: the first n*numpoints rows of level b are its curve (x, y); control (optional)
+ * double[B, max_points+1, 3]: the sorted, closed control points with their angles (the function's third result);
+ * n_out (optional) int32[B] = n*numpoints.  fp64; transcendental functions differ from numpy's in the last bits. */
+int dcd_bezier_track(const double* points, const int32_t* n_points, int32_t max_points, int32_t B, double rad, double edgy,
+                     int32_t numpoints, double* xy, double* control, int32_t* n_out, void* stream);
+
 /* ---- student policy step for rollouts (no grad) -------------------------------- */
 /* Device pointers to the fp32 parameters of the student MultigridNetwork
  * (models/multigrid_models.py:45-88, util/make_agent.py:38-47): they stay PyTorch

@@ -333,3 +333,39 @@ def env_return(agent_mean, agent_max, adv_mean, adv_max, mode=0):
     out = np.zeros_like(a)
     lib().orc_env_return(_p(a), _p(b), _p(c), _p(d), _p(out), C.c_int32(a.shape[0]), C.c_int32(mode))
     return out
+
+
+class VecNormalizeRet:
+    """numpy restatement of VecNormalize(ob=False, ret=True) (envs/wrappers/vec_normalize.py:24-45,56-70) over baselines'
+    RunningMeanStd (baselines/common/running_mean_std.py, third party, not in the reference tree: the standard
+    parallel-variance merge with epsilon = 1e-4 — parity unpinned for that class)."""
+
+    def __init__(self, num_envs, gamma=0.99, epsilon=1e-8, cliprew=10.0):
+        self.ret = np.zeros(num_envs)
+        self.mean, self.var, self.count = 0.0, 1.0, 1e-4
+        self.gamma, self.epsilon, self.cliprew = gamma, epsilon, cliprew
+
+    def reset(self):
+        self.ret = np.zeros_like(self.ret)
+
+    def step(self, rews, news):
+        rews = np.asarray(rews, np.float32)
+        self.ret = self.ret * self.gamma + rews
+        bm, bv, bc = np.mean(self.ret), np.var(self.ret), self.ret.shape[0]
+        delta, tot = bm - self.mean, self.count + bc
+        m2 = self.var * self.count + bv * bc + np.square(delta) * self.count * bc / tot
+        self.mean, self.var, self.count = self.mean + delta * bc / tot, m2 / tot, tot
+        out = np.clip(rews / np.sqrt(self.var + self.epsilon), -self.cliprew, self.cliprew)
+        self.ret[np.asarray(news, bool)] = 0.0
+        return out
+
+
+def bezier_curve(points, rad=0.2, edgy=0.2, numpoints=40):
+    """envs/box2d/bezier.py:get_bezier_curve for one level: (x, y, a) with a = [n+1, 3] sorted closed control points + angles."""
+    pts = np.ascontiguousarray(points, np.float64)
+    n = pts.shape[0]
+    xy = np.zeros((n * numpoints, 2), np.float64)
+    ctrl = np.zeros((n + 1, 3), np.float64)
+    m = lib().orc_bezier_curve(_p(pts), C.c_int32(n), C.c_double(rad), C.c_double(edgy), C.c_int32(numpoints), _p(xy), _p(ctrl))
+    assert m == n * numpoints
+    return xy[:, 0].copy(), xy[:, 1].copy(), ctrl

@@ -401,9 +401,77 @@ def gen_entropy():
     print("entropy.npz", len(out), "calls", len(calls))
 
 
+def gen_popart():
+    """models/popart.py:20-103 and its use by RolloutStorage (algos/storage.py:240-256,301-306): moments after three
+    updates, normalize / denormalize / forward, GAE returns and batched value loss on denormalised value predictions."""
+    from models.popart import PopArt
+    from algos import RolloutStorage
+    torch.manual_seed(4)
+    pa = PopArt(6, 1)
+    out = {"w0": pa.weight.detach().numpy().copy(), "b0": pa.bias.detach().numpy().copy()}
+    rng = np.random.default_rng(21)
+    for i in range(3):
+        x = (rng.standard_normal((64, 1)) * (1 + 2 * i) + 3 * i).astype(np.float32)
+        pa.update(torch.from_numpy(x))
+        out[f"upd{i}_x"] = x
+        for k in ("weight", "bias", "stddev", "mean", "mean_sq", "debiasing_term"):
+            out[f"upd{i}_{k}"] = getattr(pa, k).detach().numpy().copy()
+    q = rng.standard_normal((10, 1)).astype(np.float32)
+    feats = rng.standard_normal((10, 6)).astype(np.float32)
+    out.update(q=q, feats=feats, normalize=pa.normalize(torch.from_numpy(q)).detach().numpy(),
+               denormalize=pa.denormalize(torch.from_numpy(q)).detach().numpy(),
+               forward=pa(torch.from_numpy(feats)).detach().numpy())
+    obs_space, act_space = student_spaces()
+    T, B = 40, 8
+    d = synth_rollout(np.random.default_rng(0), T, B)
+
+    class _Model:
+        popart = pa
+    st = RolloutStorage(_Model(), T, B, obs_space, act_space, 256, recurrent_arch="lstm", use_popart=True)
+    fill_storage(st, d)
+    nv = torch.from_numpy(rng.standard_normal((B, 1)).astype(np.float32))
+    st.compute_returns(nv, True, 0.995, 0.95)
+    out.update({f"roll_{k}": v for k, v in d.items()})
+    out.update(next_value=nv.numpy(), gae=st.returns.numpy().copy(), denorm=st.denorm_value_preds.detach().numpy().copy(),
+               vl_abs=st.get_batched_value_loss().detach().numpy(), vl_pos=st.get_batched_value_loss(positive_only=True).detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "popart.npz"), **out)
+    print("popart.npz", len(out))
+
+
+def gen_bezier():
+    """envs/box2d/bezier.py:get_bezier_curve with the arguments CarRacingBezier passes (car_racing_bezier.py:297-303):
+    random control-point sets of 3..12 points (the env's own generator, get_random_points, scaled to the playfield) and
+    adversary-style sets on the 10 x 10 sketch grid (car_racing_adversarial.py:236-244)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_bezier", os.path.join(REF, "envs", "box2d", "bezier.py"))
+    bz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bz)
+    rng = np.random.RandomState(3)
+    out, k = {}, 0
+    for n in (3, 4, 5, 7, 9, 12, 12, 12):
+        a = bz.get_random_points(n=n, scale=2000 / 6.0, np_random=rng)
+        x, y, ctrl = bz.get_bezier_curve(a=a, rad=0.2, edgy=0.2, numpoints=40)
+        out[f"c{k}_pts"], out[f"c{k}_x"], out[f"c{k}_y"], out[f"c{k}_a"] = a, x, y, ctrl
+        k += 1
+    ratio = (2000 / 6.0) / 10
+    for n in (5, 8, 12, 12):                       # distinct cells of the adversary's sketch, un-normalised as the env does
+        cells = rng.permutation(100)[:n]
+        a = np.array([((c % 10 + 1) * ratio, (c // 10 + 1) * ratio) for c in cells], dtype=np.float64)
+        x, y, ctrl = bz.get_bezier_curve(a=a, rad=0.2, edgy=0.2, numpoints=40)
+        out[f"c{k}_pts"], out[f"c{k}_x"], out[f"c{k}_y"], out[f"c{k}_a"] = a, x, y, ctrl
+        k += 1
+    out["n_cases"] = np.array(k)
+    np.savez_compressed(os.path.join(OUT, "bezier.npz"), **out)
+    print("bezier.npz", k, "curves")
+
+
 if __name__ == "__main__":
+    import numpy.ma  # noqa: F401  (must be imported BEFORE the alias shims: numpy 2 uses np.bool as a dtype there)
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot  # noqa: F401  (envs/box2d/bezier.py imports it at module level)
     install_shims()
     torch.set_num_threads(1)
-    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy"]     # name the sets to (re)generate
+    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy", "popart", "bezier"]     # name the sets to (re)generate
     for name in todo:
         globals()["gen_" + name]()
