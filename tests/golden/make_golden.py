@@ -465,6 +465,45 @@ def gen_bezier():
     print("bezier.npz", k, "curves")
 
 
+def _digest(p):
+    """shape, fp64 sum, fp64 sum of squares and the first 8 entries of a tensor (keeps the fixture small)."""
+    a = p.detach().numpy().astype(np.float64).ravel()
+    return np.concatenate([np.array(p.shape, np.float64), [a.sum(), (a * a).sum()], a[:8]])
+
+
+def gen_f4_nets():
+    """models/car_racing_models.py:18-165 and models/walker_models.py:113-167,345-376: initial weights from a fixed seed and
+    evaluate_actions / get_value on fixed inputs (deterministic: no sampling)."""
+    from models.car_racing_models import CarRacingNetwork
+    from models.walker_models import BipedalWalkerStudentPolicy
+    rng = np.random.default_rng(12)
+    out = {}
+    act3 = Box((3,))
+    act3.low, act3.high = np.array([-1.0, 0.0, 0.0]), np.array([1.0, 1.0, 1.0])
+    for tag, kw, hw in (("cr", dict(), 96), ("crpop", dict(use_popart=True), 96), ("crcrop", dict(crop=True), 84)):
+        torch.manual_seed(0)
+        net = CarRacingNetwork((4, hw, hw), act3, **kw)
+        x = rng.random((2, 4, hw, hw)).astype(np.float32)
+        a = rng.random((2, 3)).astype(np.float32) * 0.98 + 0.01
+        with torch.no_grad():
+            v, lp, ent, _ = net.evaluate_actions(torch.from_numpy(x), None, None, torch.from_numpy(a))
+        out.update({f"{tag}_w_{k}": _digest(p) for k, p in net.state_dict().items()})     # 0.4M weights per net: digests
+        out.update({f"{tag}_x": x, f"{tag}_a": a, f"{tag}_value": v.numpy(), f"{tag}_logp": lp.numpy(), f"{tag}_ent": np.array(ent.item()),
+                    f"{tag}_proc": net.process_action(a)})
+    act4 = Box((4,))
+    torch.manual_seed(0)
+    net = BipedalWalkerStudentPolicy((24,), act4)
+    x = rng.standard_normal((7, 24)).astype(np.float32)
+    a = rng.standard_normal((7, 4)).astype(np.float32)
+    with torch.no_grad():
+        v, lp, ent, _ = net.evaluate_actions(torch.from_numpy(x), None, None, torch.from_numpy(a))
+        det = net.act(torch.from_numpy(x), None, None, deterministic=True)
+    out.update({f"bw_w_{k}": p.detach().numpy().copy() for k, p in net.state_dict().items()})
+    out.update(bw_x=x, bw_a=a, bw_value=v.numpy(), bw_logp=lp.numpy(), bw_ent=np.array(ent.item()), bw_mode=det[1].numpy(), bw_mode_logp=det[2].numpy())
+    np.savez_compressed(os.path.join(OUT, "f4_nets.npz"), **out)
+    print("f4_nets.npz", len(out))
+
+
 if __name__ == "__main__":
     import numpy.ma  # noqa: F401  (must be imported BEFORE the alias shims: numpy 2 uses np.bool as a dtype there)
     import matplotlib
@@ -472,6 +511,6 @@ if __name__ == "__main__":
     import matplotlib.pyplot  # noqa: F401  (envs/box2d/bezier.py imports it at module level)
     install_shims()
     torch.set_num_threads(1)
-    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy", "popart", "bezier"]     # name the sets to (re)generate
+    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy", "popart", "bezier", "f4_nets"]     # name the sets to (re)generate
     for name in todo:
         globals()["gen_" + name]()
