@@ -42,14 +42,16 @@ class RolloutStorage:
         z = lambda *s, **kw: torch.zeros(*s, device=d, **kw)
         self.is_dict_obs = isinstance(observation_space, dict)
         self.truncated_obs = None
+        self.obs_u8 = self.truncated_obs_u8 = None       # u8 mode (enable_u8_obs): what the engine writes; fp32 derived
+        self._stale = None
         if self.is_dict_obs:
-            self.obs = {k: z(T + 1, B, *sp.shape) for k, sp in observation_space.items()}
+            self._obs = {k: z(T + 1, B, *sp.shape) for k, sp in observation_space.items()}
             if use_proper_time_limits:
                 self.truncated_obs = {k: z(T + 1, B, *sp.shape) for k, sp in observation_space.items()}
         else:
-            self.obs = z(T + 1, B, *observation_space.shape)
+            self._obs = z(T + 1, B, *observation_space.shape)
             if use_proper_time_limits:
-                self.truncated_obs = torch.zeros_like(self.obs)
+                self.truncated_obs = torch.zeros_like(self._obs)
         hs = 2 * recurrent_hidden_state_size if self.is_lstm else recurrent_hidden_state_size
         self.recurrent_hidden_states = z(T + 1, B, hs)
         self.rewards = z(T, B, 1)
@@ -88,24 +90,92 @@ class RolloutStorage:
         return self
 
     # ---- observation access ---------------------------------------------------------------
+    # u8 mode (student storages of device rollouts): the engine writes the RAW observation — the encoding bytes
+    # [vx][vy][c] and the direction byte, 76 B per env-step instead of the 304 B of the preprocessed fp32 CHW image — into
+    # `obs_u8` / `truncated_obs_u8`; the fused policy step reads those bytes directly (dcd_policy_features_u8).  The
+    # reference's fp32 tensors (`obs`, what VecPreprocessImageWrapper hands over, obs_wrappers.py:88-115) are DERIVED:
+    # rows are converted on demand (one step for `get_obs`, the whole rollout once per PPO update) by
+    # dcd_obs_u8_to_f32, bit-identical to what the engine's own fp32 emission writes.
+    def enable_u8_obs(self):
+        if self.obs_u8 is not None or not self.is_dict_obs or set(self._obs) != {"image", "direction"}:
+            return self.obs_u8 is not None
+        T1, B, d = self.num_steps + 1, self.num_processes, self.device
+        V = self._obs["image"].shape[-1]
+        mk = lambda: {"image": torch.zeros((T1, B, V, V, 3), dtype=torch.uint8, device=d),
+                      "direction": torch.zeros((T1, B), dtype=torch.uint8, device=d)}
+        self.obs_u8 = mk()
+        self._stale = [False] * T1
+        if self.truncated_obs is not None:
+            self.truncated_obs_u8 = mk()
+        return True
+
+    def _convert(self, src, dst, sl):
+        import ctypes as C
+        from dcd_hip import check, lib, ptr, stream_ptr
+        img8, dir8 = src["image"][sl], src["direction"][sl]
+        n, V = img8.numel() // (img8.shape[-1] * img8.shape[-2] * img8.shape[-3]), img8.shape[-2]
+        check(lib().dcd_obs_u8_to_f32(ptr(img8, torch.uint8), ptr(dir8, torch.uint8), ptr(dst["image"][sl], torch.float32),
+                                      ptr(dst["direction"][sl], torch.float32), C.c_int64(n), C.c_int32(V), stream_ptr()))
+
+    def mark_obs_stale(self):
+        """Every fp32 row is out of date (a HIP-graph replay rewrote the u8 buffers without passing through Python)."""
+        if self.obs_u8 is not None:
+            self._stale = [True] * (self.num_steps + 1)
+
+    def sync_obs(self, idx=None):
+        """Brings the fp32 observation rows up to date with the u8 ones (all stale time steps, or just `idx`)."""
+        if self.obs_u8 is None:
+            return
+        if idx is not None:
+            idx = idx % (self.num_steps + 1)
+            if self._stale[idx]:
+                self._convert(self.obs_u8, self._obs, slice(idx, idx + 1))
+                self._stale[idx] = False
+            return
+        t, T1 = 0, self.num_steps + 1
+        while t < T1:                                     # contiguous runs of stale steps, one launch each
+            if not self._stale[t]:
+                t += 1
+                continue
+            e = t
+            while e < T1 and self._stale[e]:
+                self._stale[e] = False
+                e += 1
+            self._convert(self.obs_u8, self._obs, slice(t, e))
+            t = e
+
+    @property
+    def obs(self):
+        self.sync_obs()
+        return self._obs
+
     def get_obs(self, idx):
-        return {k: v[idx] for k, v in self.obs.items()} if self.is_dict_obs else self.obs[idx]
+        self.sync_obs(idx)
+        return {k: v[idx] for k, v in self._obs.items()} if self.is_dict_obs else self._obs[idx]
 
     def copy_obs_to_index(self, obs, index):
+        if self.obs_u8 is not None:
+            raise RuntimeError("storage in u8 observation mode: fp32 observations are derived; write obs_u8 (engine outputs)")
         if self.is_dict_obs:
-            for k in self.obs:
-                self.obs[k][index].copy_(obs[k])
+            for k in self._obs:
+                self._obs[k][index].copy_(obs[k])
         else:
-            self.obs[index].copy_(obs)
+            self._obs[index].copy_(obs)
 
     def student_obs_out(self, index, truncated=False):
-        """Engine output struct whose fp32 image/direction land in obs[index] (or truncated_obs[index])."""
-        src = self.truncated_obs if truncated else self.obs
+        """Engine output struct whose image/direction land in obs[index] (or truncated_obs[index]): raw bytes in u8 mode,
+        the preprocessed fp32 otherwise."""
+        if self.obs_u8 is not None:
+            src = self.truncated_obs_u8 if truncated else self.obs_u8
+            if not truncated:
+                self._stale[index % (self.num_steps + 1)] = True
+            return {"image_u8": src["image"][index], "dir_u8": src["direction"][index]}
+        src = self.truncated_obs if truncated else self._obs
         return {"image_f32": src["image"][index], "dir_f32": src["direction"][index]}
 
     def adversary_obs_out(self, index):
-        return {"image_f32": self.obs["image"][index], "time_step": self.obs["time_step"][index],
-                "random_z": self.obs["random_z"][index]}
+        return {"image_f32": self._obs["image"][index], "time_step": self._obs["time_step"][index],
+                "random_z": self._obs["random_z"][index]}
 
     def step_out(self, step):
         """DcdStepOut for rollout step `step`: the engine writes obs[step+1], rewards[step], masks[step+1],
@@ -154,16 +224,22 @@ class RolloutStorage:
         self.step = (self.step + 1) % self.num_steps
 
     def insert_truncated_obs(self, obs, index):
+        if self.truncated_obs_u8 is not None:
+            raise RuntimeError("storage in u8 observation mode: truncated observations come from the engine")
         for k in self.truncated_obs:
             self.truncated_obs[k][self.step + 1][index].copy_(torch.as_tensor(obs[k]).reshape(
                 self.truncated_obs[k].shape[2:]))
 
     def after_update(self):
-        if self.is_dict_obs:
-            for k in self.obs:
-                self.obs[k][0].copy_(self.obs[k][-1])
+        if self.obs_u8 is not None:
+            for k in self.obs_u8:
+                self.obs_u8[k][0].copy_(self.obs_u8[k][-1])
+            self._stale[0] = True
+        elif self.is_dict_obs:
+            for k in self._obs:
+                self._obs[k][0].copy_(self._obs[k][-1])
         else:
-            self.obs[0].copy_(self.obs[-1])
+            self._obs[0].copy_(self._obs[-1])
         self.recurrent_hidden_states[0].copy_(self.recurrent_hidden_states[-1])
         self.masks[0].copy_(self.masks[-1])
         self.bad_masks[0].copy_(self.bad_masks[-1])
@@ -184,7 +260,13 @@ class RolloutStorage:
         if t_idx.numel() == 0:
             return self.truncated_value_preds
         with torch.no_grad():
-            if self.is_dict_obs:
+            if self.truncated_obs_u8 is not None:         # gather the raw rows, preprocess just those
+                g8 = {k: v[t_idx, b_idx].contiguous() for k, v in self.truncated_obs_u8.items()}
+                n = t_idx.numel()
+                obs = {"image": torch.empty((n,) + tuple(self._obs["image"].shape[2:]), device=self.device),
+                       "direction": torch.empty((n, 1), device=self.device)}
+                self._convert(g8, obs, slice(None))
+            elif self.is_dict_obs:
                 obs = {k: v[t_idx, b_idx] for k, v in self.truncated_obs.items()}
             else:
                 obs = self.truncated_obs[t_idx, b_idx]

@@ -103,6 +103,19 @@ DCD_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// float(k)/10.0f in IEEE fp32 division equals (float)((double)k/10.0) bit for bit for every byte value
+// (checked for k = 0..255; `float(k)*0.1f` does NOT, first mismatch k = 9) — computed in
+// registers so that building the LUTs needs no memory round trip.  kDiv10 documents the fp64 definition and is
+// what the parity tests compare against through the oracle.
+// The quotient is formed from 0.1f with one FMA correction (q0 = k*r; q = fma(fma(-q0, 10, k), r, q0)): equal to the
+// IEEE division for every k in 0..255 (checked on the host, tools/ and tests/test_gpu_env_parity compare every
+// observation with the oracle's true division), 5 instructions instead of the ~15 of a correctly rounded fp32 division
+// — four of them sat on the logic wave's critical path at the start of every launch.
+DCD_HD float div10f(uint32_t k) {
+  const float n = (float)k, r = 0.1f, q0 = n * r;
+  return __builtin_fmaf(__builtin_fmaf(-q0, 10.0f, n), r, q0);
+}
+
 // ---------------------------------------------------------------- packed codes
 DCD_HD bool is_wall(uint8_t c) { return c >= C_WALL0 && c < C_FLOOR0; }
 DCD_HD bool is_agent(uint8_t c) { return c >= C_AGENT0 && c < C_DOOR0; }

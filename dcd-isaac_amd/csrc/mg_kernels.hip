@@ -41,18 +41,6 @@ __device__ __forceinline__ lds_u8* as_lds(uint8_t* p) { return (lds_u8*)p; }
 
 // LUTs shared by the emission code, indexed by packed cell code: the 3 encoding bytes and their /10 floats
 struct Luts { uint32_t enc[64]; float f[3][64]; float div10[16]; };
-// float(k)/10.0f in IEEE fp32 division equals (float)((double)k/10.0) bit for bit for every byte value
-// (checked for k = 0..255; `float(k)*0.1f` does NOT, first mismatch k = 9) — computed in
-// registers so that building the LUTs needs no memory round trip.  kDiv10 documents the fp64 definition and is
-// what the parity tests compare against through the oracle.
-// The quotient is formed from 0.1f with one FMA correction (q0 = k*r; q = fma(fma(-q0, 10, k), r, q0)): equal to the
-// IEEE division for every k in 0..255 (checked on the host, tools/ and tests/test_gpu_env_parity compare every
-// observation with the oracle's true division), 5 instructions instead of the ~15 of a correctly rounded fp32 division
-// — four of them sat on the logic wave's critical path at the start of every launch.
-__device__ __forceinline__ float div10f(uint32_t k) {
-  const float n = (float)k, r = 0.1f, q0 = n * r;
-  return __builtin_fmaf(__builtin_fmaf(-q0, 10.0f, n), r, q0);
-}
 __device__ __forceinline__ void init_luts(Luts& l, int tid) {
   if (tid < 64) {
     const uint32_t t = tid < C_END ? enc3_flat((uint32_t)tid) : 0u;

@@ -31,7 +31,10 @@ constexpr int MAXV = 7, MAXF = 32, MAXH = 256, MAXA = 16;
 // ---- features ---------------------------------------------------------------------------------
 // VV/FF/EE/HH > 0: compile-time geometry (the registered student: V=5, F=16, E=5, H=256 -> K=405), so the
 // (env, k) index split is multiplications by constants; 0: runtime geometry.
-template <int VV, int FF, int EE, int HH>
+// U8: the observation arrives as the env wrote it — raw encoding bytes [vx][vy][c] and a direction byte (RolloutStorage
+// in u8 mode: 76 instead of 304 bytes per env-step through HBM) — and VecPreprocessImageWrapper's /10 + HWC->CHW
+// (obs_wrappers.py:88-115) happens while the image is staged into LDS: dcd::div10f(k) is the exact fp32 of k / 10.0.
+template <int VV, int FF, int EE, int HH, bool U8 = false>
 __global__ void __launch_bounds__(PB) policy_features_kernel(DcdStudentNet n, const float* __restrict__ image,
                                                              const float* __restrict__ direction, const float* __restrict__ hc,
                                                              const float* __restrict__ masks, float* __restrict__ x, int KP, int B) {
@@ -53,11 +56,19 @@ __global__ void __launch_bounds__(PB) policy_features_kernel(DcdStudentNet n, co
   // (c) one_hot(dim, direction) @ W^T + b (:123-125) == column `direction` of W + b: a dependent gather, started now
   if (tid < ne * E) {
     const int e = tid / E, j = tid - e * E;
-    int d = (int)direction[env0 + e];
+    int d = U8 ? (int)reinterpret_cast<const uint8_t*>(direction)[env0 + e] : (int)direction[env0 + e];
     d = d < 0 ? 0 : (d >= n.D ? n.D - 1 : d);
     s_emb[e][j] = n.embed_w[j * n.D + d] + n.embed_b[j];
   }
-  for (int q = tid; q < ne * IMG; q += PB) s_img[q / IMG][q % IMG] = image[(size_t)env0 * IMG + q];
+  if (U8) {
+    const uint8_t* img8 = reinterpret_cast<const uint8_t*>(image);
+    for (int q = tid; q < ne * IMG; q += PB) {                    // byte q of the batch = env e, cell (vx,vy), channel c
+      const int e = q / IMG, r = q - e * IMG, cell = r / 3, c = r - cell * 3;
+      s_img[e][c * V * V + cell] = dcd::div10f(img8[(size_t)env0 * IMG + q]);
+    }
+  } else {
+    for (int q = tid; q < ne * IMG; q += PB) s_img[q / IMG][q % IMG] = image[(size_t)env0 * IMG + q];
+  }
   for (int q = tid; q < F * 27; q += PB) s_w[q] = n.conv_w[q];
   for (int q = tid; q < F; q += PB) s_w[MAXF * 27 + q] = n.conv_b[q];
   __builtin_amdgcn_sched_barrier(0);                               // loads above stay batched ahead of the stores
@@ -81,6 +92,19 @@ __global__ void __launch_bounds__(PB) policy_features_kernel(DcdStudentNet n, co
         for (int kx = 0; kx < 3; ++kx) acc = fmaf(w[c * 9 + ky * 3 + kx], s_img[e][c * V * V + (oy + ky) * V + ox + kx], acc);
     x[(size_t)(env0 + e) * KP + k] = fmaxf(acc, 0.f);
   }
+}
+
+// VecPreprocessImageWrapper._preprocess (obs_wrappers.py:88-115) for N stored observations: image_f32[n][c][vx][vy] =
+// image_u8[n][vx][vy][c] / 10.0 (exact: dcd::div10f), dir_f32[n] = dir_u8[n].  One output element per thread.
+__global__ void obs_u8_to_f32_kernel(const uint8_t* __restrict__ img8, const uint8_t* __restrict__ dir8, float* __restrict__ img, float* __restrict__ dir,
+                                     long long N, int V) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int VV = V * V, IMG = 3 * VV;
+  if (q >= N * IMG) return;
+  const long long n = q / IMG;
+  const int r = (int)(q - n * IMG), c = r / VV, cell = r - c * VV;
+  img[q] = dcd::div10f(img8[n * IMG + cell * 3 + c]);
+  if (dir8 && dir && r == 0) dir[n] = (float)dir8[n];
 }
 
 // ---- features of a grid-sized observation (the teacher: 15 x 15 image, F = 128 filters, time-step embedding, z) -----
@@ -389,6 +413,31 @@ int dcd_policy_pack_heads(const DcdStudentNet* net, float* packed, void* stream)
   if (!packed) return dcd::fail("dcd_policy_pack_heads: NULL output");
   hipLaunchKernelGGL(heads_pack_kernel, dim3((PK_FLOATS + PB - 1) / PB), dim3(PB), 0, (hipStream_t)stream, *net, packed);
   if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_pack_heads: launch failed");
+  return 0;
+}
+
+int dcd_policy_features_u8(const DcdStudentNet* net, const uint8_t* image_u8, const uint8_t* dir_u8, const float* hc, const float* masks,
+                           float* x, int32_t x_pitch, int32_t B, void* stream) {
+  if (check_net(net)) return 1;
+  if (x_pitch < dcd_policy_input_width(net)) return dcd::fail("dcd_policy_features_u8: x_pitch %d < K", x_pitch);
+  if (!image_u8 || !dir_u8 || !hc || !masks || !x || B <= 0) return dcd::fail("dcd_policy_features_u8: NULL pointer or B <= 0");
+  const dim3 grid((B + FE - 1) / FE), block(PB);
+  const float* img = reinterpret_cast<const float*>(image_u8); const float* dir = reinterpret_cast<const float*>(dir_u8);
+  if (net->V == 5 && net->F == 16 && net->E == 5 && net->H == 256)
+    hipLaunchKernelGGL((policy_features_kernel<5, 16, 5, 256, true>), grid, block, 0, (hipStream_t)stream, *net, img, dir, hc, masks, x, x_pitch, B);
+  else
+    hipLaunchKernelGGL((policy_features_kernel<0, 0, 0, 0, true>), grid, block, 0, (hipStream_t)stream, *net, img, dir, hc, masks, x, x_pitch, B);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_features_u8: launch failed");
+  return 0;
+}
+
+int dcd_obs_u8_to_f32(const uint8_t* image_u8, const uint8_t* dir_u8, float* image_f32, float* dir_f32, int64_t N, int32_t V, void* stream) {
+  if (!image_u8 || !image_f32 || N < 0 || V < 1 || V > MAXV) return dcd::fail("dcd_obs_u8_to_f32: bad arguments");
+  if (N == 0) return 0;
+  const long long total = (long long)N * 3 * V * V;
+  hipLaunchKernelGGL(obs_u8_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, image_u8, dir_u8, image_f32,
+                     dir_f32, (long long)N, V);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_obs_u8_to_f32: launch failed");
   return 0;
 }
 

@@ -116,9 +116,14 @@ class StudentActor:
         log_prob [B,1], log_dist [B,NA]."""
         B, s = self.B, self._struct
         L = lib()
-        check(L.dcd_policy_features(C.byref(s), ptr(image, torch.float32, B * 3 * self._dims["V"] ** 2, "image"),
-                                    ptr(direction, torch.float32, B, "direction"), ptr(hc_in, torch.float32, B * 2 * self.H, "hc_in"),
-                                    ptr(masks, torch.float32, B, "masks"), ptr(self.x), C.c_int32(self.KP), C.c_int32(B), stream_ptr()))
+        if image.dtype == torch.uint8:                                # raw observation bytes (RolloutStorage in u8 mode)
+            check(L.dcd_policy_features_u8(C.byref(s), ptr(image, torch.uint8, B * 3 * self._dims["V"] ** 2, "image_u8"),
+                                           ptr(direction, torch.uint8, B, "dir_u8"), ptr(hc_in, torch.float32, B * 2 * self.H, "hc_in"),
+                                           ptr(masks, torch.float32, B, "masks"), ptr(self.x), C.c_int32(self.KP), C.c_int32(B), stream_ptr()))
+        else:
+            check(L.dcd_policy_features(C.byref(s), ptr(image, torch.float32, B * 3 * self._dims["V"] ** 2, "image"),
+                                        ptr(direction, torch.float32, B, "direction"), ptr(hc_in, torch.float32, B * 2 * self.H, "hc_in"),
+                                        ptr(masks, torch.float32, B, "masks"), ptr(self.x), C.c_int32(self.KP), C.c_int32(B), stream_ptr()))
         torch.addmm(self.bias, self.x, self.w_t, out=self.gates)
         check(L.dcd_policy_cell_heads(C.byref(s), ptr(self.packed), ptr(self.gates), ptr(hc_in), ptr(masks), ptr(hc_out, torch.float32, B * 2 * self.H, "hc_out"),
                                       ptr(value, torch.float32, B, "value"), ptr(action, torch.int64, B, "action"),
@@ -141,7 +146,8 @@ class StudentActor:
         algos/storage.py:155-185) without leaving the device: writes value_preds[step], actions[step],
         action_log_probs[step], action_log_dist[step], recurrent_hidden_states[step+1]."""
         self.counter = step
-        self.act_into(st.obs["image"][step], st.obs["direction"][step], st.recurrent_hidden_states[step], st.masks[step],
+        o = st.obs_u8 if st.obs_u8 is not None else st._obs
+        self.act_into(o["image"][step], o["direction"][step], st.recurrent_hidden_states[step], st.masks[step],
                       st.recurrent_hidden_states[step + 1], st.value_preds[step], st.actions[step], st.action_log_probs[step],
                       st.action_log_dist[step], deterministic=deterministic)
 

@@ -126,6 +126,12 @@ class AdversarialRunner:
         # DCD_PAIR_ROLLOUT=1 (default): in a PAIRED update without level replay the protagonist's and the antagonist's
         # rollouts advance in lock-step, ONE env-step launch for both (dcd_mg_step_pair) on two copies of the levels.
         self.pair_rollouts = os.environ.get("DCD_PAIR_ROLLOUT", "1") != "0" and self.device.type == "cuda"
+        # DCD_U8_OBS=1 (default): the students' rollout buffers hold the RAW observation bytes (76 B per env-step instead of
+        # 304 B of preprocessed fp32); the fused policy step reads them, fp32 views are derived for the PPO batch
+        if os.environ.get("DCD_U8_OBS", "1") != "0" and self.device.type == "cuda":
+            for name in ("agent", "adversary_agent"):
+                if self.agents[name] is not None:
+                    self.agents[name].storage.enable_u8_obs()
         self.use_hip_graphs = mode in ("1", "2") and self.device.type == "cuda"
         self.graph_pytorch_nets = mode == "2"       # also capture rollouts whose policy runs as PyTorch modules
         self._graphs = {}
@@ -385,13 +391,19 @@ class AdversarialRunner:
         levels = [self.level_store.get_level(s) for s in seeds]
         kind, a, b = self.venv._levels_to_device(levels)
         idx_dev = finished.to(torch.int32)
-        out = self.venv.engine.student_buffers(len(idx), u8=False)
+        u8 = st.obs_u8 is not None
+        out = self.venv.engine.student_buffers(len(idx), u8=u8, f32=not u8)
         if kind == "enc":
             self.venv.engine.reset_to_encoding(a, idx_dev, out)
         else:
             self.venv.engine.reset_to_actions(a, b, idx_dev, out)
-        st.obs["image"][step + 1][finished] = out["image_f32"]
-        st.obs["direction"][step + 1][finished] = out["dir_f32"]
+        if u8:
+            st.obs_u8["image"][step + 1][finished] = out["image_u8"]
+            st.obs_u8["direction"][step + 1][finished] = out["dir_u8"]
+            st._stale[step + 1] = True
+        else:
+            st._obs["image"][step + 1][finished] = out["image_f32"]
+            st._obs["direction"][step + 1][finished] = out["dir_f32"]
         for i, s in zip(idx, seeds):
             self.current_level_seeds[i] = s                              # this rollout's own copy (_student_rollout)
             rollout_info["solved_idx"][i] = True
@@ -413,6 +425,7 @@ class AdversarialRunner:
         else:
             self._graphed(("student", id(agent), num_steps, track_seeds, bool(agent.actor_critic.random)), num_steps, body)
         agent.storage.step = 0
+        agent.storage.mark_obs_stale()
         self.venv.raise_errors()
 
     def _fused_actor(self, agent):
@@ -483,6 +496,7 @@ class AdversarialRunner:
             body(0, num_steps)
         for a in agents:
             a.storage.step = 0
+            a.storage.mark_obs_stale()
         self.venv.raise_errors()
 
     def _paired_rollout_body(self, agents, num_steps, t0, t1, track_seeds):

@@ -366,6 +366,16 @@ int dcd_policy_input_width(const DcdStudentNet* net);
  * masks: float[B].  The caller then forms gates = x @ [W_ih | W_hh]^T + (b_ih + b_hh) (one GEMM). */
 int dcd_policy_features(const DcdStudentNet* net, const float* image, const float* direction, const float* hc,
                         const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream);
+/* dcd_policy_features reading the observation as the env wrote it: image_u8 uint8[B,V,V,3] (raw encoding, [vx][vy][c]),
+ * dir_u8 uint8[B] — the /10 and the HWC->CHW transposition of VecPreprocessImageWrapper._preprocess
+ * (obs_wrappers.py:88-115) are applied while the image is staged (exact: the fp32 nearest to k / 10.0). */
+int dcd_policy_features_u8(const DcdStudentNet* net, const uint8_t* image_u8, const uint8_t* dir_u8, const float* hc,
+                           const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream);
+/* VecPreprocessImageWrapper._preprocess (obs_wrappers.py:88-115) for N stored student observations:
+ * image_f32[n,c,vx,vy] = image_u8[n,vx,vy,c] / 10.0, dir_f32[n] = dir_u8[n] (dir pointers may both be NULL).  Used where
+ * fp32 observations are consumed in bulk (the PPO batch, the truncated-observation value pass). */
+int dcd_obs_u8_to_f32(const uint8_t* image_u8, const uint8_t* dir_u8, float* image_f32, float* dir_f32, int64_t N, int32_t V,
+                      void* stream);
 /* The same row for a grid-sized observation (the teacher, multigrid_models.py:109-139, util/make_agent.py:22-36):
  * x[b] = [relu(conv(image[b])) flattened [F][(S-2)^2] | scalar_embed(one_hot(scalar[b])) | z[b] | h[b]*masks[b]].
  * Only conv_w, conv_b, embed_w, embed_b and V (= S <= 17), F (<= 128), E, D, H of `net` are read.  image:
