@@ -56,8 +56,9 @@ def parse():
                     help="also time dcd_mg_step alone at B = 65 536 and 1 048 576, where it is HBM-bound (default: on, rank 0, N=1)")
     ap.add_argument("--no-sweep", dest="sweep", action="store_false")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a shared GPU)")
-    ap.add_argument("--obs", choices=["f32", "u8"], default="f32",
-                    help="student observations written by the step: fp32 CHW / 10 (what the nets read) or the raw u8 encoding")
+    ap.add_argument("--obs", choices=["f32", "u8"], default="u8",
+                    help="student observations written by the step: the raw u8 encoding (default: what the rollout buffers hold, "
+                         "RolloutStorage u8 mode) or the preprocessed fp32 CHW / 10")
     ap.add_argument("--no-pair", action="store_true", help="step the two students' env copies in two launches per step instead of one")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the end-to-end PAIRED leg (policy nets + PPO in the loop)")
     ap.add_argument("--train-updates", type=int, default=2, help="timed AdversarialRunner.run() calls of the end-to-end leg")
@@ -69,7 +70,7 @@ class PairedPass:
 
     N_CLUTTER = 25
 
-    def __init__(self, B, T, device, rank, pair=True, obs="f32"):
+    def __init__(self, B, T, device, rank, pair=True, obs="u8"):
         import dcd_hip
         self.pair, self.obs = pair, obs
         self.img_key, self.dir_key = ("image_u8", "dir_u8") if obs == "u8" else ("image_f32", "dir_f32")
@@ -316,7 +317,7 @@ def step_kernel_profile(ps, n=256):
     return ms / max(launches, 1) * 1e-3          # seconds per launch
 
 
-def sweep_large_b(device, sizes=(65536, 1048576), iters=30):
+def sweep_large_b(device, obs="u8", sizes=(65536, 1048576), iters=30):
     """dcd_mg_step alone at large B (HBM-bound regime), same outputs as the benchmark step."""
     import dcd_hip
     res = []
@@ -324,7 +325,7 @@ def sweep_large_b(device, sizes=(65536, 1048576), iters=30):
         eng = dcd_hip.MultiGridEngine(B, device=device, n_clutter=25, choose_goal_last=1)
         eng.reset_random()
         act = dcd_hip.engine.random_actions(B, 0, 3, 0, 7, device)
-        out = eng.step_buffers(u8=False)
+        out = eng.step_buffers(u8=(obs == "u8"), f32=(obs != "u8"))
         for _ in range(3):
             eng.step(act, 0, out)
         eng.profile_begin(iters)
@@ -333,7 +334,8 @@ def sweep_large_b(device, sizes=(65536, 1048576), iters=30):
         n, ms = eng.profile_end()
         dt = ms / n * 1e-3
         res.append(dict(envs=B, us_per_launch=dt * 1e6, env_steps_per_s=B / dt,
-                        achieved_GBs=B * STEP_ALGO_BYTES["f32"] / dt / 1e9, frac=B * STEP_ALGO_BYTES["f32"] / dt / 1e9 / HBM_PEAK_GBS))
+                        obs=obs, algorithmic_bytes_per_env_step=STEP_ALGO_BYTES[obs],
+                        achieved_GBs=B * STEP_ALGO_BYTES[obs] / dt / 1e9, frac=B * STEP_ALGO_BYTES[obs] / dt / 1e9 / HBM_PEAK_GBS))
         eng.close()
         del out
         torch.cuda.empty_cache()
@@ -452,14 +454,14 @@ def main():
         episodes = [int(a["n_eps"].sum().item()) for a in ps.agents]
         kernel_s = step_kernel_profile(ps) if rank == 0 else None
         grad_leg = grad_exchange_leg(device, world) if (dist is not None and args.dist_backend == "nccl") else None
-        sweep = sweep_large_b(device) if (args.sweep and rank == 0 and world == 1) else None
+        sweep = sweep_large_b(device, args.obs) if (args.sweep and rank == 0 and world == 1) else None
 
     if rank == 0:
         total_steps = ps.steps_per_pass() * world * args.steps
         rows = B * (2 if ps.pair else 1)                 # envs one launch of the step kernel advances
         algo = rows * STEP_ALGO_BYTES[ps.obs]
         achieved = algo / kernel_s / 1e9
-        kernel_name = f"mg_step_kernel<false,{ps.eng.step_epb(rows)},false,{'true' if ps.pair else 'false'}>"
+        kernel_name = f"mg_step_kernel<false,{ps.eng.step_epb(rows)},false,{'true' if ps.pair else 'false'},{'true' if ps.obs == 'u8' else 'false'}>"
         traffic, traffic_note = pmc_traffic(kernel_name) if B == 4096 else (None, "PMC passes are taken at 4096 envs only")
         line = {
             "metric": "env-steps/sec (whole node), MultiGrid PAIRED 4096 envs/GPU",
@@ -468,7 +470,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "MultiGrid-GoalLastFewerBlocksAdversarial-v0 PAIRED hot-path pass: teacher 27 steps + "
                                    "2 student rollouts x 256 steps + GAE + positive_value_loss episode scoring + regret; "
-                                   "Philox uniform actions, N(0,1) value predictions, no policy nets",
+                                   "Philox uniform actions, N(0,1) value predictions, no policy nets; both students' env copies "
+                                   "advance in one launch per step; observations written as " + ("raw u8 encodings" if ps.obs == "u8" else "fp32 CHW / 10"),
                        "envs_per_gpu": B, "num_steps": T, "teacher_steps": ps.Tadv, "grid": "15x15", "view": "5x5",
                        "hip_graph": graph is not None, "parallelism": f"env-sharded x{world}",
                        "env_steps_per_pass_per_gpu": ps.steps_per_pass(),
@@ -488,7 +491,13 @@ def main():
         if not args.no_train_leg and world == 1:
             del ps                                                    # free the 2 GB of benchmark buffers first
             torch.cuda.empty_cache()
-            line["end_to_end"] = end_to_end_leg(B, T, device, args.train_updates)
+            line["end_to_end"] = e2e = end_to_end_leg(B, T, device, args.train_updates)
+            # `value` is the env + scoring hot path with synthetic actions (no policy inference, no PPO).  What a user of
+            # train.py sees is next to it, never inside it:
+            line["with_policy"] = {"S_roll_env_steps_per_s": e2e["S_roll_env_steps_per_s"],
+                                   "S_train_true_env_steps_per_s": e2e["S_train_true_env_steps_per_s"],
+                                   "S_train_sps_reference_formula": e2e["S_train_sps_reference_formula"],
+                                   "note": "rollout with the policy in the loop / full PAIRED update incl. 3 PPO updates (end_to_end)"}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

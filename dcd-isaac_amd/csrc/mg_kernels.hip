@@ -41,12 +41,15 @@ __device__ __forceinline__ lds_u8* as_lds(uint8_t* p) { return (lds_u8*)p; }
 
 // LUTs shared by the emission code, indexed by packed cell code: the 3 encoding bytes and their /10 floats
 struct Luts { uint32_t enc[64]; float f[3][64]; float div10[16]; };
+template <bool FLOATS = true>
 __device__ __forceinline__ void init_luts(Luts& l, int tid) {
   if (tid < 64) {
     const uint32_t t = tid < C_END ? enc3_flat((uint32_t)tid) : 0u;
     l.enc[tid] = t;
-    l.f[0][tid] = div10f(t & 15); l.f[1][tid] = div10f((t >> 8) & 15); l.f[2][tid] = div10f((t >> 16) & 15);
-    if (tid < 16) l.div10[tid] = div10f((uint32_t)tid);
+    if (FLOATS) {                                     // only the fp32 emission reads them
+      l.f[0][tid] = div10f(t & 15); l.f[1][tid] = div10f((t >> 8) & 15); l.f[2][tid] = div10f((t >> 16) & 15);
+      if (tid < 16) l.div10[tid] = div10f((uint32_t)tid);
+    }
   }
 }
 
@@ -86,6 +89,9 @@ __device__ __forceinline__ void stage_out(const uint8_t* lds, uint8_t* __restric
 // Opaque walls (see_through == 0): the TPE threads of an env sit in one wave, so the env's see-through bit board
 // is a slice of a wave ballot; every thread then runs Grid.process_vis on it (dcd::process_vis_mask) and drops
 // its cell if unseen — no LDS, no barrier.
+// (Tried for the u8 emission and dropped after a same-box A/B: staging the bytes in LDS and writing the workgroup's block
+// with 16-byte stores — one more barrier and LDS round trip cost more than the three single-byte stores per view cell:
+// 4.40 -> 4.58 us per launch at 8192 envs, 134 -> 144 us at 1M.)
 template <int V, int ROWS, int NT>
 __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
                                             int n, int S, int tid, int see_through) {
@@ -219,7 +225,9 @@ struct StepRes { float reward, ep_ret; int ep_len; uint32_t flags; uint32_t doff
 // PAIR: the launch steps TWO replicas of the batch (dcd_mg_step_pair: the protagonist's and the antagonist's copy of the
 // levels, records / seeds / metrics contiguous: replica 1 starts at row B).  Workgroups [0, bps) serve replica 0,
 // [bps, 2 bps) replica 1; a replica has its own action array and output set, everything else is indexed by record row.
-template <bool RANDOM, int EPB, bool RR, bool PAIR = false>
+// OBS8: only the raw u8 observation is emitted (obs.image_u8 / dir_u8 and, for truncations, term_obs.image_u8): the fp32
+// tables of the emission are not built.
+template <bool RANDOM, int EPB, bool RR, bool PAIR = false, bool OBS8 = false>
 __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel(const uint8_t* __restrict__ rec_in,
                                                                                  const uint32_t* __restrict__ seed_in,
                                                                                  const int64_t* __restrict__ actions_in, int B_in,
@@ -247,7 +255,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
   if (tid < n) { seed = seed_in[row]; if (!RANDOM) act0 = ((PAIR && set) ? actions1_in : actions_in)[env]; term_valid[tid] = 0; }
   const int OP = obs_pitch(p.V);
   if (tid == 0) any_term = 0;
-  init_luts(lut, tid);
+  init_luts<!OBS8>(lut, tid);
   STAMP(1);
   if (tid < NT) stage_commit<EPB, NT>(sb, lds, n, tid);
   __syncthreads();
@@ -844,12 +852,17 @@ static int launch_step(DcdMg* h, int n_sets, const int64_t* actions0, const int6
   if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) { e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1]; h->ev_used += 2; }
   const int epb = step_epb(h->p.B * n_sets);
   const dim3 grid(((h->p.B + epb - 1) / epb) * n_sets);
-#define DCD_LAUNCH_STEP(EPB_, RR_, PAIR_) hipExtLaunchKernelGGL((mg_step_kernel<false, EPB_, RR_, PAIR_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, (const uint8_t*)h->rec, (const uint32_t*)h->seed, actions0, h->p.B, actions1, h->p, a)
-#define DCD_LAUNCH_EPB(EPB_) do { if (n_sets == 2) { if (rr) DCD_LAUNCH_STEP(EPB_, true, true); else DCD_LAUNCH_STEP(EPB_, false, true); } \
-                                  else { if (rr) DCD_LAUNCH_STEP(EPB_, true, false); else DCD_LAUNCH_STEP(EPB_, false, false); } } while (0)
+#define DCD_LAUNCH_STEP(EPB_, RR_, PAIR_, O8_) hipExtLaunchKernelGGL((mg_step_kernel<false, EPB_, RR_, PAIR_, O8_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, (const uint8_t*)h->rec, (const uint32_t*)h->seed, actions0, h->p.B, actions1, h->p, a)
+#define DCD_LAUNCH_RR(EPB_, PAIR_, O8_) do { if (rr) DCD_LAUNCH_STEP(EPB_, true, PAIR_, O8_); else DCD_LAUNCH_STEP(EPB_, false, PAIR_, O8_); } while (0)
+#define DCD_LAUNCH_EPB(EPB_) do { if (n_sets == 2) { if (obs8) DCD_LAUNCH_RR(EPB_, true, true); else DCD_LAUNCH_RR(EPB_, true, false); } \
+                                  else { if (obs8) DCD_LAUNCH_RR(EPB_, false, true); else DCD_LAUNCH_RR(EPB_, false, false); } } while (0)
   const bool rr = (flags & DCD_STEP_RESET_RANDOM) != 0;
+  // raw-u8-only emission: no set wants an fp32 image
+  auto u8_only = [&](const DcdStepOut& o) { return o.obs.image_u8 && !o.obs.image_f32 && !o.term_obs.image_f32; };
+  const bool obs8 = u8_only(a.out[0]) && (n_sets == 1 || u8_only(a.out[1]));
   if (epb == 16) DCD_LAUNCH_EPB(16); else if (epb == 32) DCD_LAUNCH_EPB(32); else DCD_LAUNCH_EPB(64);
 #undef DCD_LAUNCH_EPB
+#undef DCD_LAUNCH_RR
 #undef DCD_LAUNCH_STEP
   HIP_OK(hipGetLastError());
   return 0;

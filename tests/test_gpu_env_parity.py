@@ -120,6 +120,58 @@ def test_step_pair_matches_oracle(B, kw):
             mg_diff.compare_state(x1, y1, f"pair step {t} replica 1")
 
 
+@pytest.mark.parametrize("B,kw", [(4096, dict(n_clutter=25, choose_goal_last=1, max_episode_steps=40)),
+                                  (130, dict(n_clutter=25, choose_goal_last=1, max_episode_steps=30, see_through_walls=0)),
+                                  (77, dict(size=10, n_clutter=30, max_steps=200, max_episode_steps=40, agent_view_size=7)),
+                                  (200, dict(size=6, n_clutter=7, max_steps=50, max_episode_steps=50, agent_view_size=3)),
+                                  (32768 + 64, dict(n_clutter=25, choose_goal_last=1, max_episode_steps=25))])
+def test_u8_only_emission_matches_oracle(B, kw):
+    """The step kernel's raw-u8-only variant (what RolloutStorage's u8 mode asks for): observations staged in LDS and
+    written as 16-byte blocks, no fp32 tables — single and paired launches, ragged last workgroups, every view size,
+    opaque walls, truncated observations, every workgroup width."""
+    import torch
+    import dcd_hip
+    from tests.hip_adapter import _np
+    cfg = dict(num_envs=B, engine_seed=4, env_index_base=50)
+    cfg.update(kw)
+    x0, x1 = orc.OracleMg(**cfg), orc.OracleMg(**cfg)
+    eng_cfg = {k: v for k, v in cfg.items() if k != "num_envs"}
+    y0 = dcd_hip.MultiGridEngine(B, replicas=2, **eng_cfg)
+    y1 = y0.replica(1)
+    rng = np.random.default_rng(B)
+    for e in (x0, x1):
+        e.set_seed(np.arange(B) + 7)
+    for e in (y0, y1):
+        e.set_seed(torch.arange(B) + 7)
+    enc = mg_diff.random_encodings(rng, B, x0.S, exotic=True)
+    for e in (x0, x1):
+        e.reset_to_encoding(enc)
+    for e in (y0, y1):
+        e.reset_to_encoding(torch.from_numpy(enc).to("cuda:0"))
+    t0 = t1 = None
+    u0, u1 = y0.step_buffers(u8=True, f32=False), y1.step_buffers(u8=True, f32=False)
+    dev = lambda a: torch.as_tensor(a, dtype=torch.int64).to("cuda:0")
+    for t in range(50):
+        a0 = rng.choice(7, size=B, p=[0.15, 0.15, 0.5, 0.05, 0.05, 0.05, 0.05])
+        a1 = rng.choice(7, size=B, p=[0.2, 0.2, 0.4, 0.05, 0.05, 0.05, 0.05])
+        o0, o1 = x0.step(a0, 0, t0), x1.step(a1, 0, t1)
+        t0, t1 = o0["term_obs"], o1["term_obs"]
+        if t % 2:
+            y0.step_pair(y1, dev(a0), dev(a1), 0, u0, u1)
+        else:
+            y0.step(dev(a0), 0, u0)
+            y1.step(dev(a1), 0, u1)
+        for o, u in ((o0, u0), (o1, u1)):
+            g = _np(u)
+            for k in ("image_u8", "dir_u8"):
+                assert np.array_equal(g["obs"][k], o["obs"][k]), (t, k)
+                assert np.array_equal(g["term_obs"][k], o["term_obs"][k]), (t, "term", k)
+            for k in ("reward", "done", "info", "ep_ret", "ep_len", "masks"):
+                assert np.array_equal(g[k], o[k]), (t, k)
+    assert np.array_equal(y0.get_encodings().cpu().numpy(), x0.get_encodings())
+    assert np.array_equal(y1.get_state().cpu().numpy(), x1.get_state())
+
+
 def test_fused_random_steps_match_single_steps():
     """dcd_mg_step_random(K) == K single dcd_mg_step calls with the same Philox actions."""
     import torch

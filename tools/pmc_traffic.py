@@ -26,7 +26,7 @@ def mean_counter(d, counter, kernel="mg_step_kernel<false"):
 
 names = set()
 from bench import kernel_source_hash          # noqa: E402  (ties the numbers to the kernel source they were taken on)
-KERNEL = sys.argv[3] if len(sys.argv) > 3 else "mg_step_kernel<false,16,false,true>"
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "mg_step_kernel<false,16,false,true,true>"
 fetch_kb, nf = mean_counter(sys.argv[1], "FETCH_SIZE")
 write_kb, nw = mean_counter(sys.argv[2], "WRITE_SIZE")
 out = {"kernel": KERNEL, "kernel_names_seen": sorted(names), "source_sha256": kernel_source_hash(), "launches_sampled": [nf, nw], "FETCH_SIZE_KB_raw": fetch_kb,

@@ -16,12 +16,13 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", 
 import dcd_hip
 dcd_hip.LIB_PATH = out
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+U8 = len(sys.argv) > 2 and sys.argv[2] == "u8"
 eng = dcd_hip.MultiGridEngine(B, n_clutter=25, choose_goal_last=1)
 eng.reset_random()
 nblk = (B + 15) // 16 if B < 32 * 512 else ((B + 31) // 32 if B < 64 * 512 else (B + 63) // 64)
 st = torch.zeros((nblk, 8), dtype=torch.int64, device="cuda")
 dcd_hip.lib().dcd_internal_set_stamps(eng._h, C.c_void_p(st.data_ptr()))
-outb = eng.step_buffers(u8=False)
+outb = eng.step_buffers(u8=U8, f32=not U8)
 names = ["init_luts", "stage_in", "logic", "dyn store+writeback", "render_emit", "term emit"]
 import numpy as np
 acc = []
