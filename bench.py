@@ -61,7 +61,7 @@ def parse():
                          "RolloutStorage u8 mode) or the preprocessed fp32 CHW / 10")
     ap.add_argument("--no-pair", action="store_true", help="step the two students' env copies in two launches per step instead of one")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the end-to-end PAIRED leg (policy nets + PPO in the loop)")
-    ap.add_argument("--train-updates", type=int, default=2, help="timed AdversarialRunner.run() calls of the end-to-end leg")
+    ap.add_argument("--train-updates", type=int, default=3, help="timed AdversarialRunner.run() calls of the end-to-end leg")
     return ap.parse_args()
 
 
@@ -359,7 +359,7 @@ def end_to_end_leg(B, T, device, updates):
     agents = [make_agent(n, venv, a, device) for n in ("agent", "adversary_agent", "adversary_env")]
     runner = AdversarialRunner(args=a, venv=venv, agent=agents[0], ued_venv=ued, adversary_agent=agents[1],
                                adversary_env=agents[2], train=True, device=device)
-    for _ in range(2):                                            # warm-up: allocator, GEMM heuristics, then HIP-graph capture
+    for _ in range(3):                                            # warm-up: allocator, GEMM heuristics, HIP-graph capture, first replay
         runner.run()
     torch.cuda.synchronize()
     per_update = []
@@ -369,17 +369,19 @@ def end_to_end_leg(B, T, device, updates):
         torch.cuda.synchronize()
         per_update.append(time.perf_counter() - t0)
     dt = sum(per_update) / updates
+    # the students' rollouts as run() performs them: both in lock-step, policy in the loop, replayed from one HIP graph
     t0 = time.perf_counter()
-    runner._student_rollout(agents[0], T, False, None, {})
+    runner._paired_student_rollouts((agents[0], agents[1]), T, track_seeds=False)
     torch.cuda.synchronize()
-    roll = time.perf_counter() - t0
+    roll = (time.perf_counter() - t0) / 2                          # per student rollout of B x T env-steps
     venv.close()
     return {"S_roll_env_steps_per_s": B * T / roll, "student_rollout_ms": roll * 1e3,
             "S_train_sps_reference_formula": B * T / dt,                    # train.py:184 counts one student rollout per update
             "S_train_true_env_steps_per_s": (2 * B * T + B * 27) / dt, "seconds_per_update": dt, "updates_timed": updates,
             "seconds_each_update": [round(x, 4) for x in per_update],
             "what": "AdversarialRunner.run(), PAIRED, LSTM-256 students (433 953 params) + recurrent teacher (22 502 732 params), "
-                    "PPO 5 epochs x 1 minibatch, fp32; student rollouts: fused HIP policy step + env step replayed as HIP graphs; "
+                    "PPO 5 epochs x 1 minibatch, fp32; student rollouts: both students in lock-step (one env-step launch for both), fused HIP "
+                    "policy step on raw u8 observations, one HIP graph per rollout pair; "
                     "PPO: PyTorch-ROCm with the masked LSTM as one autograd node over HIP pointwise kernels"}
 
 
