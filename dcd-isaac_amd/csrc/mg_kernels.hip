@@ -36,6 +36,16 @@ constexpr int MAX_OP = 152;        // staged u8 obs per env: V*V*3 + dir, padded
 
 __device__ __forceinline__ int obs_pitch(int V) { return (V * V * 3 + 1 + 3) & ~3; }
 
+// Streaming (`nt`) stores for the step kernel's outputs in the BANDWIDTH regime only (64 envs per workgroup, B >= 32 768):
+// nothing in the launch reads them back, and they drain to memory while other workgroups still compute instead of sitting
+// dirty in the XCD's L2 until the end-of-kernel write-back: -3 % at B = 1M.  At B = 4096 the same stores made the pass
+// 5.5 % SLOWER (1.518 -> 1.606 ms, same-box A/B, profiles/r02_ab_nt_stores.log): there the launch is latency-bound and a
+// write-through store costs the issuing wave more than the deferred write-back costs the launch.
+template <bool NTS, class T> __device__ __forceinline__ void st_out(T* p, T v) {
+  if (NTS) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef DCD_REC uint8_t lds_u8;      // address_space(3) in the device pass, plain in the host pass
 __device__ __forceinline__ lds_u8* as_lds(uint8_t* p) { return (lds_u8*)p; }
 
@@ -98,6 +108,7 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
   // TPE threads per env (power of two >= V*V): env = slot >> log2(TPE), view cell = slot & (TPE-1) — shifts
   // and masks instead of divisions; all offsets are 32-bit from per-workgroup base pointers.
   constexpr int VV = V * V, H = V / 2, TPE = VV <= 16 ? 16 : (VV <= 32 ? 32 : 64), ITERS = (ROWS * TPE + NT - 1) / NT;
+  constexpr bool NTS = ROWS == 64;
   float* __restrict__ f32 = o.image_f32 ? o.image_f32 + out_row0 * (3 * VV) : nullptr;
   uint8_t* __restrict__ u8 = o.image_u8 ? o.image_u8 + out_row0 * (3 * VV) : nullptr;
   if (f32 || u8) {
@@ -139,20 +150,20 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
       const unsigned off = (unsigned)(row * (3 * VV) + ci);
       if (f32) {
         const float f0 = lut.f[0][c], f1 = lut.f[1][c], f2 = lut.f[2][c];
-        f32[off] = none ? 0.f : f0; f32[off + VV] = none ? 0.f : f1; f32[off + 2 * VV] = none ? 0.f : f2;
+        st_out<NTS>(&f32[off], none ? 0.f : f0); st_out<NTS>(&f32[off + VV], none ? 0.f : f1); st_out<NTS>(&f32[off + 2 * VV], none ? 0.f : f2);
       }
       if (u8) {
         const uint32_t t = none ? 0u : lut.enc[c];
         const unsigned uo = (unsigned)(row * (3 * VV) + ci * 3);
-        u8[uo] = (uint8_t)t; u8[uo + 1] = (uint8_t)(t >> 8); u8[uo + 2] = (uint8_t)(t >> 16);
+        st_out<NTS>(&u8[uo], (uint8_t)t); st_out<NTS>(&u8[uo + 1], (uint8_t)(t >> 8)); st_out<NTS>(&u8[uo + 2], (uint8_t)(t >> 16));
       }
     }
   }
   if (tid < n) {
     const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + tid * LP + DYN);
     const int d = ((dyn & 255) == NOPOS) ? 0 : ((dyn >> 16) & 255);
-    if (o.dir_u8) o.dir_u8[out_row0 + tid] = (uint8_t)d;
-    if (o.dir_f32) o.dir_f32[out_row0 + tid] = (float)d;
+    if (o.dir_u8) st_out<(ROWS == 64)>(&o.dir_u8[out_row0 + tid], (uint8_t)d);
+    if (o.dir_f32) st_out<(ROWS == 64)>(&o.dir_f32[out_row0 + tid], (float)d);
   }
 }
 template <int ROWS, int NT>
@@ -335,14 +346,14 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
       const StepRes sr = res[l];
       const uint32_t done = sr.flags & 255, info = (sr.flags >> 8) & 255;
       const DcdStepOut& o = outs;
-      if (o.reward) o.reward[ev] = sr.reward;
-      if (o.done) o.done[ev] = (uint8_t)done;
-      if (o.info) o.info[ev] = (uint8_t)info;
-      if (o.ep_ret) o.ep_ret[ev] = sr.ep_ret;
-      if (o.ep_len) o.ep_len[ev] = sr.ep_len;
-      if (o.masks) o.masks[ev] = done ? 0.f : 1.f;                                       // runner :566-573
-      if (o.bad_masks) o.bad_masks[ev] = (info & DCD_INFO_TRUNC_KEY) ? 0.f : 1.f;
-      if (o.cliffhanger_masks) o.cliffhanger_masks[ev] = (info & DCD_INFO_CLIFFHANGER) ? 0.f : 1.f;
+      if (o.reward) st_out<(EPB == 64)>(&o.reward[ev], sr.reward);
+      if (o.done) st_out<(EPB == 64)>(&o.done[ev], (uint8_t)done);
+      if (o.info) st_out<(EPB == 64)>(&o.info[ev], (uint8_t)info);
+      if (o.ep_ret) st_out<(EPB == 64)>(&o.ep_ret[ev], sr.ep_ret);
+      if (o.ep_len) st_out<(EPB == 64)>(&o.ep_len[ev], (int32_t)sr.ep_len);
+      if (o.masks) st_out<(EPB == 64)>(&o.masks[ev], done ? 0.f : 1.f);                                // runner :566-573
+      if (o.bad_masks) st_out<(EPB == 64)>(&o.bad_masks[ev], (info & DCD_INFO_TRUNC_KEY) ? 0.f : 1.f);
+      if (o.cliffhanger_masks) st_out<(EPB == 64)>(&o.cliffhanger_masks[ev], (info & DCD_INFO_CLIFFHANGER) ? 0.f : 1.f);
     }
   } else {                                           // duty wave B: record write-back
     const int l = tid - NT - WAVE;
@@ -360,13 +371,13 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
         const int nd = (sr.flags >> 20) & 3, o0 = sr.doff & 0xFFFF, o1 = sr.doff >> 16;
         const uint4 dyn = *reinterpret_cast<const uint4*>(src + DYN);
         const uint8_t c0 = src[o0], c1 = src[o1];
-        if (nd > 0) g[o0] = c0;
-        if (nd > 1) g[o1] = c1;
+        if (nd > 0) st_out<(EPB == 64)>(&g[o0], c0);
+        if (nd > 1) st_out<(EPB == 64)>(&g[o1], c1);
         if ((sr.flags >> 17) & 1) {                      // the draw counter moved (a goal was reached): side bytes of rows 8..11
 #pragma unroll
           for (int k = 8; k < 12; ++k) g[k * ROW + SIDE] = src[k * ROW + SIDE];
         }
-        *reinterpret_cast<uint4*>(g + DYN) = dyn;
+        st_out<(EPB == 64)>(reinterpret_cast<u32x4*>(g + DYN), u32x4{dyn.x, dyn.y, dyn.z, dyn.w});
       }
     }
   }
