@@ -609,16 +609,52 @@ DCD_HD void env_reset_random(Env& e, const Params& p, Metrics& m) {
   reset_agent(e);
 }
 
+// `list(set(values))` of small non-negative ints as CPython orders it (adversarial.py:327 iterates exactly that): the int is
+// its own hash, 8 slots to start with, home slot hash & mask, then the next 9 slots while they lie inside the table, then
+// i = 5 i + 1 + (perturb >>= 5); after an insertion with fill * 5 >= mask * 3 the table is rebuilt at the smallest power of
+// two above 4 * used, old entries re-inserted in table order; iteration walks the table (Objects/setobject.c).  The oracle's
+// restatement of the same is checked against the interpreter (tests/test_oracle_env.py); n <= 64 -> at most 128 slots.
+// Cold path (the level editor): the local table lives in scratch.
+DCD_HD int pyset_probe(const int16_t* table, int mask, int key, bool match) {
+  uint32_t perturb = (uint32_t)key, i = (uint32_t)key & (uint32_t)mask;
+  for (;;) {
+    if (table[i] < 0 || (match && table[i] == key)) return (int)i;
+    if (i + 9 <= (uint32_t)mask)
+      for (uint32_t j = 1; j <= 9; ++j) if (table[i + j] < 0 || (match && table[i + j] == key)) return (int)(i + j);
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & (uint32_t)mask;
+  }
+}
+DCD_HD int py_set_order(const uint8_t* values, int n, uint8_t* out) {
+  int16_t table[128], old[128];
+  int mask = 7, used = 0;
+  for (int i = 0; i < 128; ++i) table[i] = -1;
+  for (int k = 0; k < n; ++k) {
+    const int key = values[k];
+    const int slot = pyset_probe(table, mask, key, true);
+    if (table[slot] == key) continue;
+    table[slot] = (int16_t)key; ++used;
+    if (used * 5 < mask * 3) continue;
+    int newsize = 8;
+    while (newsize <= used * 4) newsize <<= 1;
+    const int oldmask = mask;
+    for (int i = 0; i <= oldmask; ++i) old[i] = table[i];
+    mask = newsize - 1;
+    for (int i = 0; i <= mask; ++i) table[i] = -1;
+    for (int i = 0; i <= oldmask; ++i) if (old[i] >= 0) table[pyset_probe(table, mask, old[i], false)] = old[i];
+  }
+  int m = 0;
+  for (int i = 0; i <= mask; ++i) if (table[i] >= 0) out[m++] = (uint8_t)table[i];
+  return m;
+}
+
 // mutate_level (adversarial.py:317-397)
 DCD_HD void env_mutate_level(Env& e, const Params& p, Metrics& m, int num_edits) {
   const int I = p.S - 2, ntiles = I * I;
-  uint8_t locs[64], acts[64]; int nloc = 0;
+  uint8_t draws[64], locs[64], acts[64];
   if (num_edits > 64) num_edits = 64;
-  for (int k = 0; k < num_edits; ++k) {
-    int l = randint(e, p, ntiles); bool dup = false;
-    for (int q = 0; q < nloc; ++q) dup |= (locs[q] == l);
-    if (!dup) locs[nloc++] = (uint8_t)l;
-  }
+  for (int k = 0; k < num_edits; ++k) draws[k] = (uint8_t)randint(e, p, ntiles);      // np.random.randint(0, num_tiles, num_edits)
+  const int nloc = py_set_order(draws, num_edits, locs);                                // list(set(...)): the set's own order
   for (int k = 0; k < nloc; ++k) acts[k] = (uint8_t)randint(e, p, p.n_editor_actions);
   uint16_t fm[13];                                  // free_mask rows (:332-334)
 #pragma unroll

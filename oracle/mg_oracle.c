@@ -483,16 +483,54 @@ static void env_reset_random(Env* e) {
   env_reset_agent(e);
 }
 
+/* ---- list(set(values)) for small non-negative ints (adversarial.py:327: `edit_locs = list(set(np.random.randint(...)))`)
+ * The order in which CPython iterates such a set is a deterministic function of the insertion sequence: hash(int) is
+ * the int, the table starts with 8 slots, a key goes to slot hash & mask, else to one of the next 9 slots (when those lie
+ * inside the table), else to the perturbed sequence i = 5 i + 1 + (perturb >>= 5); after an insertion that leaves
+ * fill * 5 >= mask * 3 the table is rebuilt with the smallest power of two above 4 * used slots, old entries re-inserted
+ * in table order; iteration walks the table (Objects/setobject.c: set_add_entry, set_insert_clean, set_table_resize).
+ * tests/test_oracle_env.py checks this restatement against the interpreter's own list(set(...)).  out gets the unique
+ * values in that order; returns their number.  n <= 64 -> at most 128 slots. */
+#define PYSET_MAX 128
+static int pyset_probe(const int* table, int mask, int key, int match) {
+  size_t perturb = (size_t)key, i = (size_t)key & (size_t)mask;
+  for (;;) {
+    if (table[i] < 0 || (match && table[i] == key)) return (int)i;
+    if (i + 9 <= (size_t)mask)
+      for (size_t j = 1; j <= 9; ++j) if (table[i + j] < 0 || (match && table[i + j] == key)) return (int)(i + j);
+    perturb >>= 5;
+    i = (i * 5 + 1 + perturb) & (size_t)mask;
+  }
+}
+int32_t orc_py_set_order(const int32_t* values, int32_t n, int32_t* out) {
+  int table[PYSET_MAX], old[PYSET_MAX], mask = 7, used = 0;
+  for (int i = 0; i < PYSET_MAX; ++i) table[i] = -1;
+  for (int k = 0; k < n; ++k) {
+    const int key = values[k];
+    const int slot = pyset_probe(table, mask, key, 1);
+    if (table[slot] == key) continue;                     /* already in the set */
+    table[slot] = key; ++used;
+    if (used * 5 < mask * 3) continue;
+    int newsize = 8;                                      /* set_table_resize(so, used * 4) */
+    while (newsize <= used * 4) newsize <<= 1;
+    memcpy(old, table, sizeof(int) * (size_t)(mask + 1));
+    const int oldmask = mask;
+    mask = newsize - 1;
+    for (int i = 0; i <= mask; ++i) table[i] = -1;
+    for (int i = 0; i <= oldmask; ++i) if (old[i] >= 0) table[pyset_probe(table, mask, old[i], 0)] = old[i];
+  }
+  int m = 0;
+  for (int i = 0; i <= mask; ++i) if (table[i] >= 0) out[m++] = table[i];
+  return m;
+}
+
 /* ---- mutate_level (adversarial.py:317-397) */
 static void env_mutate_level(Env* e, int num_edits) {
   int IW = e->W - 2, IH = e->H - 2, ntiles = IW * IH;
-  int locs[64], nloc = 0;
+  int32_t draws[64], locs[64];
   if (num_edits > 64) num_edits = 64;
-  for (int k = 0; k < num_edits; ++k) {                                   /* set(): dedup, keep first */
-    int l = env_randint(e, ntiles), dup = 0;
-    for (int q = 0; q < nloc; ++q) if (locs[q] == l) dup = 1;
-    if (!dup) locs[nloc++] = l;
-  }
+  for (int k = 0; k < num_edits; ++k) draws[k] = env_randint(e, ntiles);
+  const int nloc = orc_py_set_order(draws, num_edits, locs);                /* list(set(...)): :327 */
   int acts[64];
   for (int k = 0; k < nloc; ++k) acts[k] = env_randint(e, e->n_editor_actions);
   /* free_mask = ~wall_mask, minus agent start and goal (:332-334) */

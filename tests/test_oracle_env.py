@@ -206,3 +206,19 @@ def test_process_vis_wall_line_ahead_hides_what_is_behind(cls):
     img, _ = _opaque_view(cls, box)
     expect = np.array([[0, 0, 0, 0, 0], [0, 0, 0, 0, 0], [2, 2, 2, 2, 2], [2, 1, 1, 1, 2], [2, 1, 1, 1, 2]])
     assert np.array_equal(img, expect)
+
+
+def test_edit_locations_follow_cpython_set_order():
+    """mutate_level iterates `list(set(np.random.randint(...)))` (adversarial.py:327): which of two edits of the same kind
+    wins depends on the set's iteration order.  The oracle's restatement of CPython's set (and with it the device code,
+    compared with the oracle on every mutate call) against the interpreter's own answer, resizes included."""
+    import ctypes as C
+    L = orc.lib()
+    rng = np.random.default_rng(0)
+    for it in range(4000):
+        n = int(rng.integers(1, 65))
+        v = rng.integers(0, int(rng.choice([16, 64, 169])), n).astype(np.int64)
+        want = [int(x) for x in list(set(v))]                      # a set of np.int64 scalars, as the reference builds it
+        vi, out = v.astype(np.int32), np.zeros(64, np.int32)
+        m = L.orc_py_set_order(vi.ctypes.data_as(C.c_void_p), C.c_int32(n), out.ctypes.data_as(C.c_void_p))
+        assert out[:m].tolist() == want, (v.tolist(), want, out[:m].tolist())
