@@ -455,7 +455,12 @@ def main():
         n_recs = [int(a["scorer"].n_recs.item()) for a in ps.agents]
         episodes = [int(a["n_eps"].sum().item()) for a in ps.agents]
         kernel_s = step_kernel_profile(ps) if rank == 0 else None
-        grad_leg = grad_exchange_leg(device, world) if (dist is not None and args.dist_backend == "nccl") else None
+        grad_leg = None
+        if dist is not None and args.dist_backend == "nccl":
+            try:
+                grad_leg = grad_exchange_leg(device, world)
+            except Exception as exc:                                  # noqa: BLE001  (a side measurement must not cost the bench line)
+                grad_leg = {"error": repr(exc)}
         sweep = sweep_large_b(device, args.obs) if (args.sweep and rank == 0 and world == 1) else None
 
     if rank == 0:

@@ -533,6 +533,24 @@ DCD_HD void env_set_encoding(Env& e, const Params& p, Metrics& m, const uint8_t*
   reset_agent(e);
 }
 
+// The same from codes that the workgroup has already decoded into LDS (mg_kernels.hip: one (level, cell) pair per thread —
+// a lane decoding its 675 encoding bytes from global memory one dependent load at a time took ~0.2 ms, which a replay
+// rollout pays at every step for the handful of envs that finished an episode).  codes[i*S + j] = packed code of cell
+// (x=i, y=j); bad: this level had an undecodable cell.  Same cell order, hence the same last-agent / last-goal winners.
+DCD_HD void env_set_codes(Env& e, const Params& p, Metrics& m, const DCD_REC uint8_t* codes, bool bad, bool keep_dir = false) {
+  const int S = p.S;
+  if (bad) e.err |= DCD_ERR_BAD_ENCODING;
+  for (int i = 0; i < S; ++i) for (int j = 0; j < S; ++j) {
+    const uint8_t code = codes[i * S + j];
+    if (is_agent(code)) { e.sb(0) = (uint8_t)i; e.sb(1) = (uint8_t)j; if (keep_dir) e.sb(2) = (uint8_t)(code - C_AGENT0); }
+    else if (code == C_GOAL) { e.sb(3) = (uint8_t)i; e.sb(4) = (uint8_t)j; }
+    e.cell(i, j) = code;
+  }
+  e.full_dirty = true;
+  compute_metrics(e, p, m);
+  reset_agent(e);
+}
+
 // MultiGridEnv.reset of a FIXED level (multigrid.py:470-502 with maze.py:76-94 as _gen_grid): the grid is
 // the given encoding, the agent starts on its cell facing the encoded direction; no random draw.
 DCD_HD void env_load_fixed_level(Env& e, const Params& p, Metrics& m, const uint8_t* enc) {

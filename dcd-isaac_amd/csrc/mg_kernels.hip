@@ -433,16 +433,30 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
   __shared__ int env_of[EPB];
   __shared__ uint32_t zctr[EPB];                  // per-row rng counter at which this call's random_z starts
   __shared__ Luts lut;
+  constexpr bool DECODE = (OP == OP_SET_ENCODING || OP == OP_FIXED_LEVEL);
+  __shared__ uint8_t codes[DECODE ? EPB * MAX_SIZE * MAX_SIZE : 1];   // the rows' levels, decoded cooperatively
+  __shared__ uint32_t bad_enc[DECODE ? EPB : 1];
   const int tid = threadIdx.x, row0 = blockIdx.x * EPB;
   const int n = min(EPB, n_rows_in - row0), row = row0 + tid;
   if (tid < EPB) env_of[tid] = (tid < n) ? (idx_in ? idx_in[row] : row) : -1;
   const int S = p.S;
   init_luts(lut, tid);
+  if (DECODE && tid < EPB) bad_enc[tid] = 0;
   __syncthreads();
   {
     StageBuf<EPB, NT> sb;
     stage_load<EPB, NT>(sb, rec_in, [&](int r) { return env_of[r]; }, n, tid);
     stage_commit<EPB, NT>(sb, lds, n, tid);
+  }
+  if (DECODE) {                                   // WorldObj.decode of every cell of every row (multigrid.py:264-280), one per thread
+    const int SS = S * S;
+    for (int q = tid; q < n * SS; q += NT) {
+      const int r = q / SS, cell = q - r * SS;
+      const uint8_t* c = a.enc + ((size_t)(row0 + r) * SS + cell) * 3;
+      uint8_t code;
+      if (!dec3(c[0], c[1], c[2], &code)) { atomicOr(&bad_enc[r], 1u); code = C_NONE; }
+      codes[r * (MAX_SIZE * MAX_SIZE) + cell] = code;
+    }
   }
   __syncthreads();
 
@@ -469,9 +483,13 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
     } else if (OP == OP_SET_ENCODING) {
       env_reset(e, p, m, nullptr);                  // adversarial.py:272
       e.elapsed = 0;                                // time_limit.py:43-45
-      env_set_encoding(e, p, m, a.enc + (size_t)row * S * S * 3);
+      env_set_codes(e, p, m, as_lds(codes + tid * (MAX_SIZE * MAX_SIZE)), bad_enc[tid] != 0);
     } else if (OP == OP_FIXED_LEVEL) {
-      env_load_fixed_level(e, p, m, a.enc + (size_t)row * S * S * 3);
+      e.step_count = 0; e.sb(6) = 0;               // env_load_fixed_level with the level already decoded
+      reset_agent_status(e);
+      e.sb(0) = NOPOS; e.sb(3) = NOPOS;
+      reset_metrics(m, p);
+      env_set_codes(e, p, m, as_lds(codes + tid * (MAX_SIZE * MAX_SIZE)), bad_enc[tid] != 0, true);
       e.elapsed = 0;                                // TimeLimit.reset
       e.ep_ret = 0.f; e.ep_len = 0;                 // VecMonitor.reset (vec_monitor.py:36-40)
     } else if (OP == OP_REPLAY) {

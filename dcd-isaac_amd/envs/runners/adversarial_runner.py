@@ -420,7 +420,32 @@ class AdversarialRunner:
         if fused is not None:
             fused.begin_rollout(num_steps)
         body = lambda t0, t1: self._student_rollout_body(agent, num_steps, t0, t1, level_replay, level_sampler, rollout_info)
-        if host_resampling or (fused is None and not self.graph_pytorch_nets):
+        can_graph = self.use_hip_graphs and (fused is not None or self.graph_pytorch_nets)
+        if host_resampling and can_graph:
+            # Replay rollouts re-sample a level for every finished episode ON THE HOST between two steps (:551-558): the
+            # device part of a step (policy, env step, bookkeeping) is one small HIP graph per step index, replayed, then
+            # the host looks at the finished mask.  (Eager launches made this rollout 120 ms against 16 ms of GPU work.)
+            key = ("student-steps", id(agent), num_steps, bool(agent.actor_critic.random))
+            graphs = self._graphs.get(key)
+            dev_step = lambda t: self._student_rollout_body(agent, num_steps, t, t + 1, False, level_sampler, rollout_info)
+            if graphs is None:                                          # first replay rollout: eager, warms everything up
+                self._graphs[key] = "warm"
+                body(0, num_steps)
+            else:
+                if graphs == "warm":
+                    torch.cuda.synchronize()
+                    graphs = []
+                    for t in range(num_steps):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            dev_step(t)
+                        graphs.append(g)
+                    self._graphs[key] = graphs
+                st = agent.storage
+                for t in range(num_steps):
+                    graphs[t].replay()
+                    self._resample_finished_levels(st, t, level_sampler, rollout_info)
+        elif host_resampling or not can_graph:
             body(0, num_steps)
         else:
             self._graphed(("student", id(agent), num_steps, track_seeds, bool(agent.actor_critic.random)), num_steps, body)

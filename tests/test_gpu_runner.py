@@ -350,3 +350,35 @@ def test_paired_lockstep_training_runs_with_graphs_and_plr(monkeypatch):
     assert kinds == {True, False}
     assert any(k[0] == "pair" for k in runner._graphs)
     venv.close()
+
+
+def test_replay_rollouts_from_per_step_graphs_equal_eager_rollouts(monkeypatch):
+    """Robust PLR: a replay rollout re-samples a level for every finished episode on the host between two steps; its
+    device part runs from one small HIP graph per step index (third replay rollout on).  Same seeds, DCD_HIP_GRAPHS=1 vs
+    0: identical replay decisions, level seeds, sampler state and student storage after 14 updates."""
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DCD_HIP_GRAPHS", mode)
+        args = make_args(ued_algo="domain_randomization", use_plr=True, use_reset_random_dr=True, no_exploratory_grad_updates=True,
+                         level_replay_strategy="positive_value_loss", level_replay_score_transform="rank", level_replay_prob=0.7,
+                         level_replay_rho=0.1, level_replay_seed_buffer_size=80, staleness_coef=0.3, recurrent_adversary_env=False,
+                         num_processes=64, num_steps=60, env_name="MultiGrid-MiniGoalLastAdversarial-v0")
+        runner, venv = build(args)
+        np.random.seed(5)
+        torch.manual_seed(5)
+        replays = []
+        for _ in range(14):
+            runner.run()
+            replays.append(bool(runner.sampled_level_info["level_replay"]))
+        s = runner.level_samplers["agent"]
+        res[mode] = (replays, list(runner.current_level_seeds), s.seed_scores.copy(), s.seed_staleness.copy(), s.seeds.copy(),
+                     {k: v.clone() for k, v in _storage_tensors(runner.agents["agent"].storage).items()},
+                     any(isinstance(k, tuple) and k[0] == "student-steps" and isinstance(v, list) for k, v in runner._graphs.items()))
+        venv.close()
+    a, b = res["1"], res["0"]
+    assert sum(a[0]) >= 4 and a[6] and not b[6]                 # the per-step graphs were captured and replayed
+    assert a[0] == b[0] and a[1] == b[1]
+    for i in (2, 3, 4):
+        assert np.array_equal(a[i], b[i], equal_nan=True)
+    for k in a[5]:
+        assert torch.equal(a[5][k], b[5][k]), k
