@@ -133,11 +133,19 @@ class PairedPass:
             else:
                 eng.step(p["actions"][t], flags, outs(p, t))
                 self.twin.step(q["actions"][t], flags, outs(q, t))
-        for a in self.agents:
-            self.scans.gae_returns(a["rewards"], a["value_preds"], a["masks"], a["returns"], 0.995, 0.95)
-            a["scorer"].launch(a["returns"], a["value_preds"], a["rewards"], a["masks"], a["cliff"], a["level_seeds"],
-                               None, self.dcd_hip.SCORE_STRATEGY["positive_value_loss"], 0.995)
-            self.scans.rollout_return_stats(a["ep_ret"], a["info"], a["mean_ret"], a["max_ret"], a["n_eps"])
+        if self.pair:                 # both students' scans in one launch each (the *_batch entry points)
+            ag = self.agents
+            self.scans.gae_returns_batch([(a["rewards"], a["value_preds"], a["masks"], a["returns"]) for a in ag], 0.995, 0.95)
+            self.scans.EpisodeScorer.launch_batch([a["scorer"] for a in ag],
+                                                  [(a["returns"], a["value_preds"], a["rewards"], a["masks"], a["cliff"], a["level_seeds"], None) for a in ag],
+                                                  self.dcd_hip.SCORE_STRATEGY["positive_value_loss"], 0.995)
+            self.scans.rollout_return_stats_batch([(a["ep_ret"], a["info"], a["mean_ret"], a["max_ret"], a["n_eps"]) for a in ag])
+        else:
+            for a in self.agents:
+                self.scans.gae_returns(a["rewards"], a["value_preds"], a["masks"], a["returns"], 0.995, 0.95)
+                a["scorer"].launch(a["returns"], a["value_preds"], a["rewards"], a["masks"], a["cliff"], a["level_seeds"],
+                                   None, self.dcd_hip.SCORE_STRATEGY["positive_value_loss"], 0.995)
+                self.scans.rollout_return_stats(a["ep_ret"], a["info"], a["mean_ret"], a["max_ret"], a["n_eps"])
         p, q = self.agents
         self.scans.env_return(p["mean_ret"], p["max_ret"], q["mean_ret"], q["max_ret"], mode=0, out=self.regret)
 

@@ -9,6 +9,7 @@
 // Build with -ffp-contract=off: `a*b+c` must stay two roundings (storage.py:249-256).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <string.h>
 #include "../../include/dcd_hip.h"
 #include "dcd_internal.h"
 
@@ -20,10 +21,15 @@ constexpr int SCAN_BLOCK = 64;
 #define LOADS_ISSUED() __builtin_amdgcn_sched_barrier(0)
 constexpr int UNROLL = 32;   // time steps whose loads are in flight ahead of the dependent chain (one wave per CU at B=4096)
 
+// Batched forms (the *_batch entry points): blockIdx.y selects one of up to DCD_MAX_SCAN_SETS independent rollouts of the
+// same shape — PAIRED's protagonist and antagonist — so their scans are ONE launch each: a 4096-env scan is 64 waves on 256
+// CUs and latency-bound, two of them side by side cost the time of one.
+struct GaeSets { const float* rew[DCD_MAX_SCAN_SETS]; const float* val[DCD_MAX_SCAN_SETS]; const float* msk[DCD_MAX_SCAN_SETS]; float* ret[DCD_MAX_SCAN_SETS]; };
+
 // compute_gae_returns (algos/storage.py:249-256)
-__global__ void __launch_bounds__(SCAN_BLOCK) gae_kernel(const float* __restrict__ rew, const float* __restrict__ val,
-                                                         const float* __restrict__ msk, float* __restrict__ ret,
-                                                         int T, int B, float g, float gl) {
+__global__ void __launch_bounds__(SCAN_BLOCK) gae_kernel(GaeSets sets, int T, int B, float g, float gl) {
+  const float* __restrict__ rew = sets.rew[blockIdx.y]; const float* __restrict__ val = sets.val[blockIdx.y];
+  const float* __restrict__ msk = sets.msk[blockIdx.y]; float* __restrict__ ret = sets.ret[blockIdx.y];
   const int b = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   if (b >= B) return;
   float gae = 0.0f;
@@ -291,8 +297,10 @@ constexpr int SWEEPS = STILE / (SNT / (SE / 4));   // rows a thread loads per ar
 
 // counts[b] = 1 + #{t in [1, T) : masks[t][b] == 0}; block_sums[b / 32] = sum of counts over the 32-env block.
 // Workgroup = 64 envs x 4 time quarters (one wave each), every wave's loads in flight together.
-__global__ void __launch_bounds__(256) seg_count_par_kernel(const float* __restrict__ msk, int T, int B, int* __restrict__ counts,
-                                                            int* __restrict__ block_sums) {
+struct CountSets { const float* msk[DCD_MAX_SCAN_SETS]; int* counts[DCD_MAX_SCAN_SETS]; int* block_sums[DCD_MAX_SCAN_SETS]; };
+__global__ void __launch_bounds__(256) seg_count_par_kernel(CountSets sets, int T, int B) {
+  const float* __restrict__ msk = sets.msk[blockIdx.y]; int* __restrict__ counts = sets.counts[blockIdx.y];
+  int* __restrict__ block_sums = sets.block_sums[blockIdx.y];
   __shared__ int part[4][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int b = blockIdx.x * 64 + lane;
@@ -358,9 +366,12 @@ __device__ __forceinline__ void finish_record(DcdEpisodeRec* slot) {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));     // a plain vector: arrays of it stay in registers
 
+struct ScoreSets { ScoreArgs a[DCD_MAX_SCAN_SETS]; const int* counts[DCD_MAX_SCAN_SETS]; const int* block_sums[DCD_MAX_SCAN_SETS]; int* n_recs[DCD_MAX_SCAN_SETS]; };
 template <int ST>
-__global__ void __launch_bounds__(SNT) seg_score_lds_kernel(ScoreArgs a, const int* __restrict__ counts,
-                                                            const int* __restrict__ block_sums, int* __restrict__ n_recs) {
+__global__ void __launch_bounds__(SNT) seg_score_lds_kernel(ScoreSets sets) {
+  const ScoreArgs& a = sets.a[blockIdx.y];
+  const int* __restrict__ counts = sets.counts[blockIdx.y]; const int* __restrict__ block_sums = sets.block_sums[blockIdx.y];
+  int* __restrict__ n_recs = sets.n_recs[blockIdx.y];
   __shared__ __attribute__((aligned(16))) float s_rew[STILE][SE];
   __shared__ __attribute__((aligned(16))) float s_ret[STILE][SE];
   __shared__ __attribute__((aligned(16))) float s_val[STILE][SE];     // value_preds[t + 1]
@@ -490,9 +501,11 @@ __global__ void __launch_bounds__(SCAN_BLOCK) grounded_kernel(const DcdEpisodeRe
 }
 
 // _get_rollout_return_stats (envs/runners/adversarial_runner.py:257-271)
-__global__ void __launch_bounds__(SCAN_BLOCK) return_stats_kernel(const float* __restrict__ ep_ret, const uint8_t* __restrict__ info,
-                                                                  int T, int B, float* __restrict__ mean_r, float* __restrict__ max_r,
-                                                                  int* __restrict__ n_eps) {
+struct StatSets { const float* ep_ret[DCD_MAX_SCAN_SETS]; const uint8_t* info[DCD_MAX_SCAN_SETS]; float* mean_r[DCD_MAX_SCAN_SETS]; float* max_r[DCD_MAX_SCAN_SETS]; int* n_eps[DCD_MAX_SCAN_SETS]; };
+__global__ void __launch_bounds__(SCAN_BLOCK) return_stats_kernel(StatSets sets, int T, int B) {
+  const float* __restrict__ ep_ret = sets.ep_ret[blockIdx.y]; const uint8_t* __restrict__ info = sets.info[blockIdx.y];
+  float* __restrict__ mean_r = sets.mean_r[blockIdx.y]; float* __restrict__ max_r = sets.max_r[blockIdx.y];
+  int* __restrict__ n_eps = sets.n_eps[blockIdx.y];
   const int b = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   if (b >= B) return;
   double acc = 0.0; float mx = -INFINITY; int n = 0;
@@ -572,14 +585,25 @@ __global__ void __launch_bounds__(1024) return_normalize_kernel(float* __restric
 
 extern "C" {
 
-int dcd_gae_returns(const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T, int32_t B,
-                    double gamma, double gae_lambda, void* stream) {
-  if (!rewards || !value_preds || !masks || !returns || T <= 0 || B <= 0) return dcd::fail("dcd_gae_returns: bad arguments");
-  hipLaunchKernelGGL(gae_kernel, dim3(nblk(B)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, rewards, value_preds, masks, returns, T, B,
-                     (float)gamma, (float)(gamma * gae_lambda));
+int dcd_gae_returns_batch(int32_t n, const float* const* rewards, const float* const* value_preds, const float* const* masks,
+                          float* const* returns, int32_t T, int32_t B, double gamma, double gae_lambda, void* stream) {
+  if (n < 1 || n > DCD_MAX_SCAN_SETS || !rewards || !value_preds || !masks || !returns || T <= 0 || B <= 0)
+    return dcd::fail("dcd_gae_returns_batch: bad arguments (1 <= n <= %d)", DCD_MAX_SCAN_SETS);
+  GaeSets sets; memset(&sets, 0, sizeof sets);
+  for (int k = 0; k < n; ++k) {
+    if (!rewards[k] || !value_preds[k] || !masks[k] || !returns[k]) return dcd::fail("dcd_gae_returns_batch: null pointer in set %d", k);
+    sets.rew[k] = rewards[k]; sets.val[k] = value_preds[k]; sets.msk[k] = masks[k]; sets.ret[k] = returns[k];
+  }
+  hipLaunchKernelGGL(gae_kernel, dim3(nblk(B), n), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, sets, T, B, (float)gamma,
+                     (float)(gamma * gae_lambda));
   HIP_OK(hipGetLastError());
   return 0;
 }
+int dcd_gae_returns(const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T, int32_t B,
+                    double gamma, double gae_lambda, void* stream) {
+  return dcd_gae_returns_batch(1, &rewards, &value_preds, &masks, &returns, T, B, gamma, gae_lambda, stream);
+}
+
 int dcd_discounted_returns(const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T, int32_t B,
                            double gamma, void* stream) {
   if (!rewards || !value_preds || !masks || !returns || T <= 0 || B <= 0) return dcd::fail("dcd_discounted_returns: bad arguments");
@@ -595,52 +619,74 @@ int dcd_batched_value_loss(const float* returns, const float* value_preds, float
   return 0;
 }
 
-int dcd_episode_scores(const float* returns, const float* value_preds, const float* rewards, const float* masks,
-                       const float* cliffhanger_masks, const int32_t* level_seeds, const float* action_log_dist, int32_t T, int32_t B,
-                       int32_t A, int32_t strategy, double gamma, DcdEpisodeRec* recs, int32_t max_recs, int32_t* n_recs,
-                       int32_t* workspace, void* stream) {
-  if (!value_preds || !rewards || !masks || !cliffhanger_masks || !level_seeds || !recs || !n_recs || !workspace || T <= 0 || B <= 0)
+// one rollout's scoring arguments (dcd_episode_scores_batch)
+static int check_score_set(const DcdEpisodeScoreArgs& q, int32_t T, int32_t B, int32_t A, int32_t strategy, bool needs_logits, bool needs_returns) {
+  if (!q.value_preds || !q.rewards || !q.masks || !q.cliffhanger_masks || !q.level_seeds || !q.recs || !q.n_recs || !q.workspace || T <= 0 || B <= 0)
     return dcd::fail("dcd_episode_scores: bad arguments");
+  if (needs_logits && (!q.action_log_dist || A <= 0 || A > 16)) return dcd::fail("dcd_episode_scores: strategy %d needs action_log_dist with 1..16 actions", strategy);
+  if (needs_returns && !q.returns) return dcd::fail("dcd_episode_scores: strategy %d needs returns", strategy);
+  return 0;
+}
+
+int dcd_episode_scores_batch(int32_t n, const DcdEpisodeScoreArgs* q, int32_t T, int32_t B, int32_t A, int32_t strategy, double gamma,
+                             void* stream) {
+  if (n < 1 || n > DCD_MAX_SCAN_SETS || !q) return dcd::fail("dcd_episode_scores_batch: 1 <= n <= %d sets", DCD_MAX_SCAN_SETS);
   if (strategy < 0 || strategy > DCD_SCORE_RETURN_SUM) return dcd::fail("dcd_episode_scores: unknown strategy %d", strategy);
   const bool needs_logits = strategy == DCD_SCORE_POLICY_ENTROPY || strategy == DCD_SCORE_LEAST_CONFIDENCE || strategy == DCD_SCORE_MIN_MARGIN;
-  if (needs_logits && (!action_log_dist || A <= 0 || A > 16)) return dcd::fail("dcd_episode_scores: strategy %d needs action_log_dist with 1..16 actions", strategy);
   const bool needs_returns = strategy <= DCD_SCORE_SIGNED_VALUE_LOSS;
-  if (needs_returns && !returns) return dcd::fail("dcd_episode_scores: strategy %d needs returns", strategy);
-  int* counts = workspace; int* offsets = workspace + B;
+  for (int k = 0; k < n; ++k) if (check_score_set(q[k], T, B, A, strategy, needs_logits, needs_returns)) return 1;
   hipStream_t s = (hipStream_t)stream;
-  auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-  const bool vec_ok = aligned16(rewards) && aligned16(masks) && aligned16(cliffhanger_masks) && aligned16(level_seeds) &&
-                      aligned16(value_preds) && (!needs_returns || aligned16(returns));
-  if (!needs_logits && vec_ok && B % SE == 0 && B <= (1 << 18)) {     // staged path: [T, 32-env] tiles in LDS, 2 launches
-    int* block_sums = offsets;
-    ScoreArgs a;
-    a.ret = returns; a.val = value_preds; a.rew = rewards; a.msk = masks; a.cliff = cliffhanger_masks; a.logits = nullptr;
-    a.seeds = level_seeds; a.T = T; a.B = B; a.A = A; a.strategy = strategy; a.g = (float)gamma; a.max_entropy = 1.f; a.recs = recs; a.max_recs = max_recs;
+  auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  bool staged = !needs_logits && B % SE == 0 && B <= (1 << 18);
+  for (int k = 0; k < n && staged; ++k)
+    staged = aligned16(q[k].rewards) && aligned16(q[k].masks) && aligned16(q[k].cliffhanger_masks) && aligned16(q[k].level_seeds) &&
+             aligned16(q[k].value_preds) && (!needs_returns || aligned16(q[k].returns));
+  auto fill = [&](ScoreArgs& a, const DcdEpisodeScoreArgs& x) {
+    a.ret = x.returns; a.val = x.value_preds; a.rew = x.rewards; a.msk = x.masks; a.cliff = x.cliffhanger_masks; a.logits = x.action_log_dist;
+    a.seeds = x.level_seeds; a.T = T; a.B = B; a.A = A; a.strategy = strategy; a.g = (float)gamma; a.recs = x.recs; a.max_recs = x.max_recs;
+    a.max_entropy = A > 1 ? (float)(-(1.0 / A) * log(1.0 / A) * A) : 1.f;       // level_sampler.py:281, evaluated in fp64 like numpy
     a.offsets = nullptr;
-    hipLaunchKernelGGL(seg_count_par_kernel, dim3((B + 63) / 64), dim3(256), 0, s, masks, T, B, counts, block_sums);
+  };
+  if (staged) {                                       // [T, 32-env] tiles in LDS, 2 launches for all n sets
+    ScoreSets sets; memset(&sets, 0, sizeof sets);
+    CountSets cs; memset(&cs, 0, sizeof cs);
+    for (int k = 0; k < n; ++k) {
+      int* counts = q[k].workspace; int* block_sums = q[k].workspace + B;
+      fill(sets.a[k], q[k]); sets.a[k].logits = nullptr;
+      sets.counts[k] = counts; sets.block_sums[k] = block_sums; sets.n_recs[k] = q[k].n_recs;
+      cs.msk[k] = q[k].masks; cs.counts[k] = counts; cs.block_sums[k] = block_sums;
+    }
+    hipLaunchKernelGGL(seg_count_par_kernel, dim3((B + 63) / 64, n), dim3(256), 0, s, cs, T, B);
     switch (strategy) {
-#define DCD_SCORE_CASE(ST) case ST: hipLaunchKernelGGL(seg_score_lds_kernel<ST>, dim3(B / SE), dim3(SNT), 0, s, a, (const int*)counts, (const int*)block_sums, n_recs); break;
+#define DCD_SCORE_CASE(ST) case ST: hipLaunchKernelGGL(seg_score_lds_kernel<ST>, dim3(B / SE, n), dim3(SNT), 0, s, sets); break;
       DCD_SCORE_CASE(0) DCD_SCORE_CASE(1) DCD_SCORE_CASE(2) DCD_SCORE_CASE(6) DCD_SCORE_CASE(7) DCD_SCORE_CASE(8)
 #undef DCD_SCORE_CASE
     }
     HIP_OK(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(seg_count_kernel, dim3(nblk(B)), dim3(SCAN_BLOCK), 0, s, masks, T, B, counts);
-  hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, counts, offsets, B, n_recs);
-  ScoreArgs a;
-  a.ret = returns; a.val = value_preds; a.rew = rewards; a.msk = masks; a.cliff = cliffhanger_masks; a.logits = action_log_dist;
-  a.seeds = level_seeds; a.T = T; a.B = B; a.A = A; a.strategy = strategy; a.g = (float)gamma; a.recs = recs; a.max_recs = max_recs;
-  a.max_entropy = A > 1 ? (float)(-(1.0 / A) * log(1.0 / A) * A) : 1.f;       // level_sampler.py:281, evaluated in fp64 like numpy
-  a.offsets = offsets;
-  switch (strategy) {
+  for (int k = 0; k < n; ++k) {                       // one env per lane (logit strategies, odd batch sizes): per set
+    int* counts = q[k].workspace; int* offsets = q[k].workspace + B;
+    hipLaunchKernelGGL(seg_count_kernel, dim3(nblk(B)), dim3(SCAN_BLOCK), 0, s, q[k].masks, T, B, counts);
+    hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, counts, offsets, B, q[k].n_recs);
+    ScoreArgs a; fill(a, q[k]); a.offsets = offsets;
+    switch (strategy) {
 #define DCD_SCORE_CASE(ST) case ST: hipLaunchKernelGGL(seg_score_kernel<ST>, dim3(nblk(B)), dim3(SCAN_BLOCK), 0, s, a); break;
-    DCD_SCORE_CASE(0) DCD_SCORE_CASE(1) DCD_SCORE_CASE(2) DCD_SCORE_CASE(3) DCD_SCORE_CASE(4)
-    DCD_SCORE_CASE(5) DCD_SCORE_CASE(6) DCD_SCORE_CASE(7) DCD_SCORE_CASE(8)
+      DCD_SCORE_CASE(0) DCD_SCORE_CASE(1) DCD_SCORE_CASE(2) DCD_SCORE_CASE(3) DCD_SCORE_CASE(4)
+      DCD_SCORE_CASE(5) DCD_SCORE_CASE(6) DCD_SCORE_CASE(7) DCD_SCORE_CASE(8)
 #undef DCD_SCORE_CASE
+    }
   }
   HIP_OK(hipGetLastError());
   return 0;
+}
+
+int dcd_episode_scores(const float* returns, const float* value_preds, const float* rewards, const float* masks,
+                       const float* cliffhanger_masks, const int32_t* level_seeds, const float* action_log_dist, int32_t T, int32_t B,
+                       int32_t A, int32_t strategy, double gamma, DcdEpisodeRec* recs, int32_t max_recs, int32_t* n_recs,
+                       int32_t* workspace, void* stream) {
+  DcdEpisodeScoreArgs q = {returns, value_preds, rewards, masks, cliffhanger_masks, level_seeds, action_log_dist, recs, max_recs, n_recs, workspace};
+  return dcd_episode_scores_batch(1, &q, T, B, A, strategy, gamma, stream);
 }
 
 int dcd_return_normalize(float* rewards, const uint8_t* done, double* ret, double* rms, double gamma, double epsilon, double cliprew,
@@ -660,12 +706,24 @@ int dcd_grounded_scores(const DcdEpisodeRec* recs, int32_t n, const float* groun
   return 0;
 }
 
+int dcd_rollout_return_stats_batch(int32_t n, const float* const* ep_ret, const uint8_t* const* info, int32_t T, int32_t B,
+                                   float* const* mean_return, float* const* max_return, int32_t* const* n_episodes, void* stream) {
+  if (n < 1 || n > DCD_MAX_SCAN_SETS || !ep_ret || !info || !mean_return || !max_return || T <= 0 || B <= 0)
+    return dcd::fail("dcd_rollout_return_stats_batch: bad arguments (1 <= n <= %d)", DCD_MAX_SCAN_SETS);
+  StatSets sets; memset(&sets, 0, sizeof sets);
+  for (int k = 0; k < n; ++k) {
+    if (!ep_ret[k] || !info[k] || !mean_return[k] || !max_return[k]) return dcd::fail("dcd_rollout_return_stats_batch: null pointer in set %d", k);
+    sets.ep_ret[k] = ep_ret[k]; sets.info[k] = info[k]; sets.mean_r[k] = mean_return[k]; sets.max_r[k] = max_return[k];
+    sets.n_eps[k] = n_episodes ? n_episodes[k] : nullptr;
+  }
+  hipLaunchKernelGGL(return_stats_kernel, dim3(nblk(B), n), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, sets, T, B);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
 int dcd_rollout_return_stats(const float* ep_ret, const uint8_t* info, int32_t T, int32_t B, float* mean_return, float* max_return,
                              int32_t* n_episodes, void* stream) {
   if (!ep_ret || !info || !mean_return || !max_return || T <= 0 || B <= 0) return dcd::fail("dcd_rollout_return_stats: bad arguments");
-  hipLaunchKernelGGL(return_stats_kernel, dim3(nblk(B)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, ep_ret, info, T, B, mean_return, max_return, n_episodes);
-  HIP_OK(hipGetLastError());
-  return 0;
+  return dcd_rollout_return_stats_batch(1, &ep_ret, &info, T, B, &mean_return, &max_return, n_episodes ? &n_episodes : nullptr, stream);
 }
 
 int dcd_env_return(const float* agent_mean, const float* agent_max, const float* adv_mean, const float* adv_max, float* out, int32_t B,

@@ -34,6 +34,20 @@ def gae_returns(rewards, value_preds, masks, returns, gamma, gae_lambda):
     return returns
 
 
+def _ptr_array(ptrs):
+    return (C.c_void_p * len(ptrs))(*[p.value if p is not None else None for p in ptrs])
+
+
+def gae_returns_batch(sets, gamma, gae_lambda):
+    """`gae_returns` for up to two rollouts of one shape in ONE launch (PAIRED's protagonist and antagonist):
+    sets = [(rewards, value_preds, masks, returns), ...]."""
+    T, B = sets[0][0].shape[0], sets[0][0].shape[1]
+    cols = [[_tb(st[0], T, B, "rewards") for st in sets], [_tb(st[1], T + 1, B, "value_preds") for st in sets],
+            [_tb(st[2], T + 1, B, "masks") for st in sets], [_tb(st[3], T + 1, B, "returns") for st in sets]]
+    check(lib().dcd_gae_returns_batch(C.c_int32(len(sets)), *[_ptr_array(c) for c in cols], C.c_int32(T), C.c_int32(B),
+                                      C.c_double(gamma), C.c_double(gae_lambda), stream_ptr()))
+
+
 def discounted_returns(rewards, value_preds, masks, returns, gamma):
     """algos/storage.py:258-276 — writes returns[0:T+1]."""
     T, B = rewards.shape[0], rewards.shape[1]
@@ -51,6 +65,11 @@ def batched_value_loss(returns, value_preds, mode=0, power=1, clipped=True, out=
                                        ptr(out, torch.float32, B, "out"), C.c_int32(T), C.c_int32(B), C.c_int32(mode),
                                        C.c_int32(power), C.c_int32(int(clipped)), stream_ptr()))
     return out
+
+
+class ScoreArgs(C.Structure):          # DcdEpisodeScoreArgs
+    _fields_ = [(k, C.c_void_p) for k in ("returns", "value_preds", "rewards", "masks", "cliffhanger_masks", "level_seeds",
+                                          "action_log_dist", "recs")] + [("max_recs", C.c_int32), ("n_recs", C.c_void_p), ("workspace", C.c_void_p)]
 
 
 class EpisodeScorer:
@@ -77,6 +96,27 @@ class EpisodeScorer:
             _tb(cliffhanger_masks, T + 1, B, "cliffhanger_masks"), _tb(level_seeds, T, B, "level_seeds", torch.int32),
             ld, C.c_int32(T), C.c_int32(B), C.c_int32(A), C.c_int32(strategy), C.c_double(gamma),
             ptr(self.recs), C.c_int32(self.max_recs), ptr(self.n_recs), ptr(self.workspace), stream_ptr()))
+
+    @staticmethod
+    def launch_batch(scorers, argsets, strategy, gamma):
+        """`launch` of up to two scorers of one (T, B) on their own rollouts in one launch sequence:
+        argsets[k] = (returns, value_preds, rewards, masks, cliffhanger_masks, level_seeds, action_log_dist)."""
+        T, B = scorers[0].T, scorers[0].B
+        arr = (ScoreArgs * len(scorers))()
+        A = 0
+        for k, (sc, a) in enumerate(zip(scorers, argsets)):
+            ld = None
+            if a[6] is not None:
+                A = a[6].shape[-1]
+                ld = ptr(a[6], torch.float32, T * B * A, "action_log_dist")
+            vals = [_tb(a[0], T + 1, B, "returns"), _tb(a[1], T + 1, B, "value_preds"), _tb(a[2], T, B, "rewards"),
+                    _tb(a[3], T + 1, B, "masks"), _tb(a[4], T + 1, B, "cliffhanger_masks"), _tb(a[5], T, B, "level_seeds", torch.int32), ld,
+                    ptr(sc.recs)]
+            for name, v in zip(("returns", "value_preds", "rewards", "masks", "cliffhanger_masks", "level_seeds", "action_log_dist", "recs"), vals):
+                setattr(arr[k], name, v.value if v is not None else None)
+            arr[k].max_recs, arr[k].n_recs, arr[k].workspace = sc.max_recs, ptr(sc.n_recs).value, ptr(sc.workspace).value
+        check(lib().dcd_episode_scores_batch(C.c_int32(len(scorers)), arr, C.c_int32(T), C.c_int32(B), C.c_int32(A), C.c_int32(strategy),
+                                             C.c_double(gamma), stream_ptr()))
 
     def records(self):
         """Synchronises: returns the records as a numpy structured array (reference order)."""
@@ -106,6 +146,15 @@ def rollout_return_stats(ep_ret, info, mean_out=None, max_out=None, n_out=None):
                                          C.c_int32(T), C.c_int32(B), ptr(mean_out, torch.float32, B), ptr(max_out, torch.float32, B),
                                          ptr(n_out, torch.int32, B), stream_ptr()))
     return mean_out, max_out, n_out
+
+
+def rollout_return_stats_batch(sets):
+    """`rollout_return_stats` for up to two rollouts in one launch: sets = [(ep_ret, info, mean_out, max_out, n_out), ...]."""
+    T, B = sets[0][0].shape
+    cols = [[ptr(st[0], torch.float32, T * B, "ep_ret") for st in sets], [ptr(st[1], torch.uint8, T * B, "info") for st in sets],
+            [ptr(st[2], torch.float32, B) for st in sets], [ptr(st[3], torch.float32, B) for st in sets], [ptr(st[4], torch.int32, B) for st in sets]]
+    a = [_ptr_array(c) for c in cols]
+    check(lib().dcd_rollout_return_stats_batch(C.c_int32(len(sets)), a[0], a[1], C.c_int32(T), C.c_int32(B), a[2], a[3], a[4], stream_ptr()))
 
 
 def env_return(agent_mean, agent_max, adv_mean, adv_max, mode=0, out=None):

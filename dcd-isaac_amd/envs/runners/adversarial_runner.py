@@ -201,10 +201,10 @@ class AdversarialRunner:
                 self.weighted_num_edits = self._get_weighted_num_edits()
 
     # ---- stats ---------------------------------------------------------------------------------
-    def _rollout_return_stats(self, storage):
+    def _rollout_return_stats(self, storage, device_stats=None):
         """Per-env mean / max of the episode returns of this rollout (:257-271), on device; plus the
         last <=10 returns in the reference's append order for the running mean (:845-853)."""
-        mean, mx, n = scans.rollout_return_stats(storage.ep_ret, storage.ep_info)
+        mean, mx, n = device_stats if device_stats is not None else scans.rollout_return_stats(storage.ep_ret, storage.ep_info)
         info = storage.ep_info.t().cpu().numpy()                     # [B,T]
         rets = storage.ep_ret.t().cpu().numpy()
         b_idx, t_idx = np.nonzero(info & dcd_hip.INFO_EPISODE)       # env-major, time ascending
@@ -523,6 +523,20 @@ class AdversarialRunner:
             a.storage.step = 0
             a.storage.mark_obs_stale()
         self.venv.raise_errors()
+        # both students' return statistics — and, when training, their returns — from one launch each (the *_batch scans)
+        B = self.args.num_processes
+        outs = [(torch.empty((B, 1), device=self.device), torch.empty((B, 1), device=self.device),
+                 torch.empty((B,), dtype=torch.int32, device=self.device)) for _ in agents]
+        scans.rollout_return_stats_batch([(a.storage.ep_ret, a.storage.ep_info) + o for a, o in zip(agents, outs)])
+        self._pair_cache = {id(a): {"stats": o} for a, o in zip(agents, outs)}
+        if self.is_training:
+            with torch.no_grad():
+                nvs = [a.get_value(a.storage.get_obs(-1), a.storage.get_recurrent_hidden_state(-1), a.storage.masks[-1]).detach()
+                       for a in agents]
+            type(agents[0].storage).compute_returns_batch([a.storage for a in agents], nvs, self.args.use_gae, self.args.gamma,
+                                                          self.args.gae_lambda)
+            for a in agents:
+                self._pair_cache[id(a)]["returns"] = True
 
     def _paired_rollout_body(self, agents, num_steps, t0, t1, track_seeds):
         args, venv = self.args, self.venv
@@ -593,18 +607,22 @@ class AdversarialRunner:
             self._flush_updates()
         if level_sampler and level_replay:
             rollout_info["solved_idx"] = np.zeros(B, dtype=bool)
+        cache = {}
         if not rollout_done:
             self._student_rollout(agent, num_steps, level_replay, level_sampler, rollout_info)
-        stats = self._rollout_return_stats(agent.storage)
+        else:
+            cache = getattr(self, "_pair_cache", {}).pop(id(agent), {})
+        stats = self._rollout_return_stats(agent.storage, cache.get("stats"))
         rollout_info.update(stats)
         self.total_episodes_collected += stats["total_episodes"]
         if self.is_dr and not args.use_plr:
             self.total_seeds_collected += stats["total_episodes"]
         if update:
             st = agent.storage
-            with torch.no_grad():
-                next_value = agent.get_value(st.get_obs(-1), st.get_recurrent_hidden_state(-1), st.masks[-1]).detach()
-            st.compute_returns(next_value, args.use_gae, args.gamma, args.gae_lambda)
+            if not cache.get("returns"):
+                with torch.no_grad():
+                    next_value = agent.get_value(st.get_obs(-1), st.get_recurrent_hidden_state(-1), st.masks[-1]).detach()
+                st.compute_returns(next_value, args.use_gae, args.gamma, args.gae_lambda)
             if self.requires_batched_vloss:
                 clipped = not args.adv_use_popart and not args.adv_normalize_returns
                 rollout_info["batched_value_loss"] = st.get_batched_value_loss(

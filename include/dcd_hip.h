@@ -242,6 +242,11 @@ int dcd_mg_get_state(DcdMg* h, int32_t* out, void* stream);
 int dcd_gae_returns(const float* rewards, const float* value_preds, const float* masks,
                     float* returns, int32_t T, int32_t B, double gamma, double gae_lambda,
                     void* stream);
+/* The same scan for n <= DCD_MAX_SCAN_SETS independent rollouts of one shape in ONE launch (PAIRED: the protagonist's and
+ * the antagonist's storages, adversarial_runner.py:604-605 after each of the two rollouts); pointer arrays in HOST memory. */
+#define DCD_MAX_SCAN_SETS 2
+int dcd_gae_returns_batch(int32_t n, const float* const* rewards, const float* const* value_preds, const float* const* masks,
+                          float* const* returns, int32_t T, int32_t B, double gamma, double gae_lambda, void* stream);
 /* compute_discounted_returns (storage.py:258-276): ret[T] = v[T];
  * ret[t] = ((ret[t+1]*gamma)*m[t+1]) + r[t]. */
 int dcd_discounted_returns(const float* rewards, const float* value_preds, const float* masks,
@@ -294,6 +299,15 @@ int dcd_episode_scores(const float* returns, const float* value_preds, const flo
                        DcdEpisodeRec* recs, int32_t max_recs, int32_t* n_recs,
                        int32_t* workspace, void* stream);
 
+/* dcd_episode_scores for n <= DCD_MAX_SCAN_SETS rollouts of one shape in one launch sequence (one record buffer each). */
+typedef struct DcdEpisodeScoreArgs {
+  const float* returns; const float* value_preds; const float* rewards; const float* masks; const float* cliffhanger_masks;
+  const int32_t* level_seeds; const float* action_log_dist;
+  DcdEpisodeRec* recs; int32_t max_recs; int32_t* n_recs; int32_t* workspace;
+} DcdEpisodeScoreArgs;
+int dcd_episode_scores_batch(int32_t n, const DcdEpisodeScoreArgs* sets, int32_t T, int32_t B, int32_t A, int32_t strategy,
+                             double gamma, void* stream);
+
 /* grounded_signed/positive_value_loss (level_sampler.py:351-424), second pass once the host
  * has resolved each record's grounded value g = max(grounded_values[seed_idx], reward_sum)
  * (:533-538): adv_t = g - V[t, actor] over the record's steps (dense: first step only),
@@ -312,6 +326,9 @@ int dcd_grounded_scores(const DcdEpisodeRec* recs, int32_t n, const float* groun
 int dcd_rollout_return_stats(const float* ep_ret, const uint8_t* info, int32_t T, int32_t B,
                              float* mean_return, float* max_return, int32_t* n_episodes,
                              void* stream);
+int dcd_rollout_return_stats_batch(int32_t n, const float* const* ep_ret, const uint8_t* const* info, int32_t T, int32_t B,
+                                   float* const* mean_return, float* const* max_return, int32_t* const* n_episodes,
+                                   void* stream);
 /* _compute_env_return (adversarial_runner.py:637-674), mode 0 paired
  * max(antag_max - protag_mean, 0); 1 flexible_paired; 2 minimax (-protag_max). */
 int dcd_env_return(const float* agent_mean, const float* agent_max, const float* adv_mean,

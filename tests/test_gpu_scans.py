@@ -212,3 +212,43 @@ def test_return_stats_and_regret_match_oracle():
     for mode in (0, 1, 2):
         out = scans.env_return(*[dev(x) for x in a], mode=mode).cpu().numpy()
         assert np.array_equal(bits(out), bits(orc.env_return(*a, mode=mode)))
+
+
+def test_batched_scans_equal_the_single_launches():
+    """dcd_gae_returns_batch / dcd_episode_scores_batch / dcd_rollout_return_stats_batch over two rollouts (PAIRED's two
+    students) == the single-rollout entry points, bit for bit; staged scoring path and the one-env-per-lane fallback."""
+    from dcd_hip import scans
+    for (T, B, strategy, with_logits) in ((256, 4096, 1, False), (37, 96, 6, False), (40, 77, 1, False), (64, 64, 4, True)):
+        sets = []
+        for k in range(2):
+            rng, r, v, m = _big(T, B, seed=20 + k)
+            m = (rng.random((T + 1, B)) < 0.97).astype(np.float32)
+            m[0] = 1
+            m[T][rng.random(B) < 0.6] = 0
+            cliff = (rng.random((T + 1, B)) < 0.8).astype(np.float32)
+            seeds = rng.integers(1, 999, (T, B)).astype(np.int32)
+            info = ((rng.random((T, B)) < 0.03) * 1).astype(np.uint8)
+            ep = rng.random((T, B)).astype(np.float32)
+            ld = rng.standard_normal((T, B, 7)).astype(np.float32) if with_logits else None
+            sets.append(dict(r=dev(r), v=dev(v), m=dev(m), cliff=dev(cliff), seeds=dev(seeds), info=dev(info), ep=dev(ep),
+                             ld=dev(ld) if ld is not None else None))
+        single, batch = [], []
+        for s_ in sets:                                               # single launches
+            ret = torch.zeros((T + 1, B), device=DEV)
+            scans.gae_returns(s_["r"], s_["v"], s_["m"], ret, 0.995, 0.95)
+            sc = scans.EpisodeScorer(T, B, DEV)
+            sc.launch(ret, s_["v"], s_["r"], s_["m"], s_["cliff"], s_["seeds"], s_["ld"], strategy, 0.995)
+            st = scans.rollout_return_stats(s_["ep"], s_["info"])
+            single.append((ret, sc.records(), [x.clone() for x in st]))
+        rets = [torch.zeros((T + 1, B), device=DEV) for _ in sets]
+        scans.gae_returns_batch([(s_["r"], s_["v"], s_["m"], rets[k]) for k, s_ in enumerate(sets)], 0.995, 0.95)
+        scs = [scans.EpisodeScorer(T, B, DEV) for _ in sets]
+        scans.EpisodeScorer.launch_batch(scs, [(rets[k], s_["v"], s_["r"], s_["m"], s_["cliff"], s_["seeds"], s_["ld"]) for k, s_ in enumerate(sets)], strategy, 0.995)
+        outs = [(torch.zeros((B, 1), device=DEV), torch.zeros((B, 1), device=DEV), torch.zeros(B, dtype=torch.int32, device=DEV)) for _ in sets]
+        scans.rollout_return_stats_batch([(s_["ep"], s_["info"]) + outs[k] for k, s_ in enumerate(sets)])
+        for k in range(2):
+            assert torch.equal(rets[k][:-1], single[k][0][:-1])
+            a, b = scs[k].records(), single[k][1]
+            assert len(a) == len(b) > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            for x, y in zip(outs[k], single[k][2]):
+                assert torch.equal(x.view(-1), y.view(-1))
