@@ -85,7 +85,9 @@ class PairedPass:
         self.Tadv = self.N_CLUTTER + 2
         z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=device)
         # teacher rollout buffers (obs of step k+1 written by step k; adversarial_runner.py:481,515)
-        self.adv = dict(image=z(self.Tadv + 1, B, 3, 15, 15), time_step=z(self.Tadv + 1, B, 1),
+        self.adv_key = "image_u8" if obs == "u8" else "image_f32"     # the teacher's full-grid observation: raw bytes or fp32 CHW / 10
+        self.adv = dict(image=(z(self.Tadv + 1, B, 15, 15, 3, dt=torch.uint8) if obs == "u8" else z(self.Tadv + 1, B, 3, 15, 15)),
+                        time_step=z(self.Tadv + 1, B, 1),
                         random_z=z(self.Tadv + 1, B, 50), done=z(self.Tadv, B, dt=torch.uint8),
                         loc=z(self.Tadv, B, dt=torch.int64))
         gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -112,11 +114,11 @@ class PairedPass:
     def run(self):
         """Issues every launch of one pass on the current stream; no host synchronisation."""
         eng, T, B, adv, ra = self.eng, self.T, self.B, self.adv, self.dcd_hip.engine.random_actions
-        eng.reset(dict(image_f32=adv["image"][0], time_step=adv["time_step"][0], random_z=adv["random_z"][0]))
+        eng.reset({self.adv_key: adv["image"][0], "time_step": adv["time_step"][0], "random_z": adv["random_z"][0]})
         ra(B, self.base, 2, 0, eng.n_adv_actions, self.dev, out=adv["loc"], T=self.Tadv)      # synthetic teacher actions
         for k in range(self.Tadv):
-            eng.step_adversary(adv["loc"][k], dict(image_f32=adv["image"][k + 1], time_step=adv["time_step"][k + 1],
-                                                   random_z=adv["random_z"][k + 1], done=adv["done"][k]))
+            eng.step_adversary(adv["loc"][k], {self.adv_key: adv["image"][k + 1], "time_step": adv["time_step"][k + 1],
+                                               "random_z": adv["random_z"][k + 1], "done": adv["done"][k]})
         # protagonist and antagonist play the teacher's levels in independent rollouts (adversarial_runner.py:709-733):
         # each on its own copy of the env records, both advanced by ONE launch per step
         self.twin.clone_levels(eng)

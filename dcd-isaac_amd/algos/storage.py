@@ -97,12 +97,19 @@ class RolloutStorage:
     # rows are converted on demand (one step for `get_obs`, the whole rollout once per PPO update) by
     # dcd_obs_u8_to_f32, bit-identical to what the engine's own fp32 emission writes.
     def enable_u8_obs(self):
-        if self.obs_u8 is not None or not self.is_dict_obs or set(self._obs) != {"image", "direction"}:
+        """Students: image + direction as bytes.  The teacher (image, time_step, random_z): the full-grid image as bytes
+        (675 instead of 2 700 B per env-step), the two small float entries stay as they are."""
+        if self.obs_u8 is not None or not self.is_dict_obs or "image" not in self._obs or self._obs["image"].dim() != 5:
             return self.obs_u8 is not None
         T1, B, d = self.num_steps + 1, self.num_processes, self.device
         V = self._obs["image"].shape[-1]
-        mk = lambda: {"image": torch.zeros((T1, B, V, V, 3), dtype=torch.uint8, device=d),
-                      "direction": torch.zeros((T1, B), dtype=torch.uint8, device=d)}
+        has_dir = "direction" in self._obs
+
+        def mk():
+            o = {"image": torch.zeros((T1, B, V, V, 3), dtype=torch.uint8, device=d)}
+            if has_dir:
+                o["direction"] = torch.zeros((T1, B), dtype=torch.uint8, device=d)
+            return o
         self.obs_u8 = mk()
         self._stale = [False] * T1
         if self.truncated_obs is not None:
@@ -112,10 +119,12 @@ class RolloutStorage:
     def _convert(self, src, dst, sl):
         import ctypes as C
         from dcd_hip import check, lib, ptr, stream_ptr
-        img8, dir8 = src["image"][sl], src["direction"][sl]
+        img8 = src["image"][sl]
         n, V = img8.numel() // (img8.shape[-1] * img8.shape[-2] * img8.shape[-3]), img8.shape[-2]
-        check(lib().dcd_obs_u8_to_f32(ptr(img8, torch.uint8), ptr(dir8, torch.uint8), ptr(dst["image"][sl], torch.float32),
-                                      ptr(dst["direction"][sl], torch.float32), C.c_int64(n), C.c_int32(V), stream_ptr()))
+        has_dir = "direction" in src
+        check(lib().dcd_obs_u8_to_f32(ptr(img8, torch.uint8), ptr(src["direction"][sl], torch.uint8) if has_dir else None,
+                                      ptr(dst["image"][sl], torch.float32),
+                                      ptr(dst["direction"][sl], torch.float32) if has_dir else None, C.c_int64(n), C.c_int32(V), stream_ptr()))
 
     def mark_obs_stale(self):
         """Every fp32 row is out of date (a HIP-graph replay rewrote the u8 buffers without passing through Python)."""
@@ -174,8 +183,21 @@ class RolloutStorage:
         return {"image_f32": src["image"][index], "dir_f32": src["direction"][index]}
 
     def adversary_obs_out(self, index):
+        if self.obs_u8 is not None:
+            self._stale[index % (self.num_steps + 1)] = True
+            return {"image_u8": self.obs_u8["image"][index], "time_step": self._obs["time_step"][index],
+                    "random_z": self._obs["random_z"][index]}
         return {"image_f32": self._obs["image"][index], "time_step": self._obs["time_step"][index],
                 "random_z": self._obs["random_z"][index]}
+
+    def rollout_obs(self, idx):
+        """Observation of step `idx` as the rollout-time HIP policy paths read it: the image as raw bytes in u8 mode (no
+        conversion), everything else as stored."""
+        if self.obs_u8 is None:
+            return self.get_obs(idx)
+        o = {k: v[idx] for k, v in self._obs.items() if k not in self.obs_u8}
+        o.update({k: v[idx] for k, v in self.obs_u8.items()})
+        return o
 
     def step_out(self, step):
         """DcdStepOut for rollout step `step`: the engine writes obs[step+1], rewards[step], masks[step+1],
@@ -234,6 +256,9 @@ class RolloutStorage:
         if self.obs_u8 is not None:
             for k in self.obs_u8:
                 self.obs_u8[k][0].copy_(self.obs_u8[k][-1])
+            for k in self._obs:
+                if k not in self.obs_u8:                                  # entries that are not kept as bytes (teacher: time_step, random_z)
+                    self._obs[k][0].copy_(self._obs[k][-1])
             self._stale[0] = True
         elif self.is_dict_obs:
             for k in self._obs:

@@ -113,6 +113,9 @@ __global__ void obs_u8_to_f32_kernel(const uint8_t* __restrict__ img8, const uin
 // write P consecutive floats of the row.  Row layout as the module's cat (multigrid_models.py:119-131):
 // [relu(conv) flattened [F][P] | scalar_embed(one_hot(scalar)) | random_z | h * mask], pitch KP.
 constexpr int GMAXS = 17, GMAXF = 128;
+// U8: image is the raw full-grid encoding uint8[B,S,S,3] ([x][y][c], what the teacher's rollout buffer holds in u8 mode);
+// the /10 and HWC->CHW of the preprocessing wrapper happen while it is staged (dcd::div10f: exact).
+template <bool U8>
 __global__ void __launch_bounds__(PB) grid_features_kernel(DcdStudentNet n, const float* __restrict__ image, const float* __restrict__ scalar,
                                                            const float* __restrict__ z, int Z, const float* __restrict__ hc,
                                                            const float* __restrict__ masks, float* __restrict__ x, int KP, int B) {
@@ -127,7 +130,12 @@ __global__ void __launch_bounds__(PB) grid_features_kernel(DcdStudentNet n, cons
   if (tid < H) hv = hc[(size_t)b * 2 * H + tid] * m;
   if (tid < E) { int d = (int)scalar[b]; d = d < 0 ? 0 : (d >= n.D ? n.D - 1 : d); ev = n.embed_w[tid * n.D + d] + n.embed_b[tid]; }
   if (tid < Z) zv = z[(size_t)b * Z + tid];
-  for (int q = tid; q < IMG; q += PB) s_img[q] = image[(size_t)b * IMG + q];
+  if (U8) {
+    const uint8_t* img8 = reinterpret_cast<const uint8_t*>(image) + (size_t)b * IMG;
+    for (int q = tid; q < IMG; q += PB) { const int cell = q / 3, c = q - cell * 3; s_img[c * S * S + cell] = dcd::div10f(img8[q]); }
+  } else {
+    for (int q = tid; q < IMG; q += PB) s_img[q] = image[(size_t)b * IMG + q];
+  }
   for (int q = tid; q < F * 27; q += PB) s_w[q] = n.conv_w[q];
   for (int q = tid; q < F; q += PB) s_w[GMAXF * 27 + q] = n.conv_b[q];
   if (tid < E) row[CF + tid] = ev;
@@ -393,19 +401,28 @@ int dcd_policy_features(const DcdStudentNet* net, const float* image, const floa
   return 0;
 }
 
-int dcd_policy_grid_features(const DcdStudentNet* net, const float* image, const float* scalar, const float* z, int32_t z_dim,
-                             const float* hc, const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream) {
+static int grid_features(const DcdStudentNet* net, const void* image, bool u8, const float* scalar, const float* z, int32_t z_dim,
+                         const float* hc, const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream) {
   if (!net) return dcd::fail("dcd_policy_grid_features: net is NULL");
   const int P = (net->V - 2) * (net->V - 2);
   if (net->V < 3 || net->V > GMAXS || P > PB || net->F < 1 || net->F > GMAXF) return dcd::fail("dcd_policy_grid_features: unsupported conv geometry S=%d F=%d", net->V, net->F);
   if (net->H < 1 || net->H > PB || net->E < 0 || net->E > PB || net->D < 1 || z_dim < 0 || z_dim > PB) return dcd::fail("dcd_policy_grid_features: unsupported widths");
   if (!image || !scalar || !hc || !masks || !x || (z_dim && !z) || B <= 0) return dcd::fail("dcd_policy_grid_features: NULL pointer or B <= 0");
   if (x_pitch < net->F * P + net->E + z_dim + net->H) return dcd::fail("dcd_policy_grid_features: x_pitch %d too small", x_pitch);
-  hipLaunchKernelGGL(grid_features_kernel, dim3(B), dim3(PB), 0, (hipStream_t)stream, *net, image, scalar, z, z_dim, hc, masks, x, x_pitch, B);
+  const float* img = reinterpret_cast<const float*>(image);
+  if (u8) hipLaunchKernelGGL(grid_features_kernel<true>, dim3(B), dim3(PB), 0, (hipStream_t)stream, *net, img, scalar, z, z_dim, hc, masks, x, x_pitch, B);
+  else hipLaunchKernelGGL(grid_features_kernel<false>, dim3(B), dim3(PB), 0, (hipStream_t)stream, *net, img, scalar, z, z_dim, hc, masks, x, x_pitch, B);
   if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_grid_features: launch failed");
   return 0;
 }
-
+int dcd_policy_grid_features(const DcdStudentNet* net, const float* image, const float* scalar, const float* z, int32_t z_dim,
+                             const float* hc, const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream) {
+  return grid_features(net, image, false, scalar, z, z_dim, hc, masks, x, x_pitch, B, stream);
+}
+int dcd_policy_grid_features_u8(const DcdStudentNet* net, const uint8_t* image_u8, const float* scalar, const float* z, int32_t z_dim,
+                                const float* hc, const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream) {
+  return grid_features(net, image_u8, true, scalar, z, z_dim, hc, masks, x, x_pitch, B, stream);
+}
 int dcd_policy_packed_heads_floats(void) { return PK_FLOATS; }
 
 int dcd_policy_pack_heads(const DcdStudentNet* net, float* packed, void* stream) {
@@ -432,7 +449,7 @@ int dcd_policy_features_u8(const DcdStudentNet* net, const uint8_t* image_u8, co
 }
 
 int dcd_obs_u8_to_f32(const uint8_t* image_u8, const uint8_t* dir_u8, float* image_f32, float* dir_f32, int64_t N, int32_t V, void* stream) {
-  if (!image_u8 || !image_f32 || N < 0 || V < 1 || V > MAXV) return dcd::fail("dcd_obs_u8_to_f32: bad arguments");
+  if (!image_u8 || !image_f32 || N < 0 || V < 1 || V > DCD_MAX_GRID) return dcd::fail("dcd_obs_u8_to_f32: bad arguments");
   if (N == 0) return 0;
   const long long total = (long long)N * 3 * V * V;
   hipLaunchKernelGGL(obs_u8_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, image_u8, dir_u8, image_f32,

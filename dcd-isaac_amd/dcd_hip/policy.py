@@ -152,6 +152,23 @@ class StudentActor:
                       st.action_log_dist[step], deterministic=deterministic)
 
 
+_DIV10 = {}
+
+
+def _div10_lut(device):
+    """k -> fp32(k / 10.0) for every byte: VecPreprocessImageWrapper's scale (obs_wrappers.py:90-91), exact."""
+    key = str(device)
+    if key not in _DIV10:
+        import numpy as np
+        _DIV10[key] = torch.from_numpy((np.arange(256, dtype=np.float64) / 10.0).astype(np.float32)).to(device)
+    return _DIV10[key]
+
+
+def _u8_to_chw(img8):
+    """[n,S,S,3] raw encoding -> the preprocessed [n,3,S,S] float image (small inputs only: first frames)."""
+    return _div10_lut(img8.device)[img8.long()].permute(0, 3, 1, 2).contiguous()
+
+
 def incremental_act_enabled():
     """DCD_INCREMENTAL_ACT=0: the teacher's rollout multiplies the dense 21 632-wide operand at every step."""
     return os.environ.get("DCD_INCREMENTAL_ACT", "1") != "0"
@@ -244,15 +261,17 @@ class GridActor:
         S, F = self._dims["V"], self._dims["F"]
         O = S - 2
         P = O * O
+        u8 = image.dtype == torch.uint8              # raw encoding [B,S,S,3] ([x][y][c]) instead of the preprocessed [B,3,S,S]
         if prev_image is None:
             if not bool((image == image[:1]).all()):                               # (host sync)
                 return False
-            self._xp_img = (net.image_conv(image[:1]) @ self._lstm.weight_ih_l0[:, :F * P].t()).expand(B, G).contiguous()
+            first = _u8_to_chw(image[:1]) if u8 else image[:1]
+            self._xp_img = (net.image_conv(first) @ self._lstm.weight_ih_l0[:, :F * P].t()).expand(B, G).contiguous()
             return True
         if self._xp_img is None:
             return False
         dev = image.device
-        changed = (image != prev_image).any(dim=1)                                 # [B,S,S]
+        changed = (image != prev_image).any(dim=-1 if u8 else 1)                   # [B,S,S] over (x, y) either way
         dirty = Fn.max_pool2d(changed.float().unsqueeze(1), 3, 1).squeeze(1) > 0   # [B,O,O]: conv positions that see a change
         nn_, oy, ox = dirty.nonzero(as_tuple=True)                                 # (host sync) rows in (env, position) order
         M = nn_.numel()
@@ -270,12 +289,17 @@ class GridActor:
         slot_u[order] = slot
         src[nn_, rank] = slot_u.to(torch.int32)
         k = torch.arange(3, device=dev)
-        offs = (torch.arange(3, device=dev).view(3, 1, 1) * S * S + k.view(1, 3, 1) * S + k.view(1, 1, 3)).reshape(-1)
-        col = (oy[order] * S + ox[order]).unsqueeze(1) + offs.unsqueeze(0)         # [M, 27]: the 3x3x3 window of each pair
+        if u8:                                                                     # element (c, k1, k2) of the window at byte ((y+k1)*S + x+k2)*3 + c
+            offs = (torch.arange(3, device=dev).view(3, 1, 1) + (k.view(1, 3, 1) * S + k.view(1, 1, 3)) * 3).reshape(-1)
+            col = ((oy[order] * S + ox[order]) * 3).unsqueeze(1) + offs.unsqueeze(0)
+        else:
+            offs = (torch.arange(3, device=dev).view(3, 1, 1) * S * S + k.view(1, 3, 1) * S + k.view(1, 1, 3)).reshape(-1)
+            col = (oy[order] * S + ox[order]).unsqueeze(1) + offs.unsqueeze(0)     # [M, 27]: the 3x3x3 window of each pair
         conv = net.image_conv[0]
         wc = conv.weight.view(F, -1).t()
         rows = n_s.unsqueeze(1)
-        feat = lambda im: torch.relu(torch.addmm(conv.bias, im.reshape(B, -1)[rows, col], wc))
+        window = (lambda im: _div10_lut(dev)[im.reshape(B, -1)[rows, col].long()]) if u8 else (lambda im: im.reshape(B, -1)[rows, col])
+        feat = lambda im: torch.relu(torch.addmm(conv.bias, window(im), wc))
         dpad = torch.zeros((P * cmax, F), device=dev).index_copy_(0, slot, feat(image) - feat(prev_image))
         y = torch.bmm(dpad.view(P, cmax, F), self.wp).view(P * cmax, G)
         check(lib().dcd_gather_sum_rows(ptr(y, torch.float32), ptr(src, torch.int32), ptr(self._xp_img, torch.float32), C.c_int32(B),
@@ -324,8 +348,10 @@ class GridActor:
         if scalar is None:
             scalar = obs.get("time_step")
         z = obs.get("random_z") if self.Z else None
-        check(lib().dcd_policy_grid_features(
-            C.byref(s), ptr(obs["image"], torch.float32, B * 3 * self._dims["V"] ** 2, "image"), ptr(scalar, torch.float32, B, "scalar"),
+        u8 = obs["image"].dtype == torch.uint8
+        fn = lib().dcd_policy_grid_features_u8 if u8 else lib().dcd_policy_grid_features
+        check(fn(
+            C.byref(s), ptr(obs["image"], torch.uint8 if u8 else torch.float32, B * 3 * self._dims["V"] ** 2, "image"), ptr(scalar, torch.float32, B, "scalar"),
             ptr(z, torch.float32, B * self.Z, "random_z") if z is not None else None, C.c_int32(self.Z),
             ptr(hc_in, torch.float32, B * 2 * H, "hc_in"), ptr(masks, torch.float32, B, "masks"), ptr(self.x), C.c_int32(self.KP),
             C.c_int32(B), stream_ptr()))

@@ -129,9 +129,9 @@ class AdversarialRunner:
         # DCD_U8_OBS=1 (default): the students' rollout buffers hold the RAW observation bytes (76 B per env-step instead of
         # 304 B of preprocessed fp32); the fused policy step reads them, fp32 views are derived for the PPO batch
         if os.environ.get("DCD_U8_OBS", "1") != "0" and self.device.type == "cuda":
-            for name in ("agent", "adversary_agent"):
+            for name in ("agent", "adversary_agent", "adversary_env"):
                 if self.agents[name] is not None:
-                    self.agents[name].storage.enable_u8_obs()
+                    self.agents[name].storage.enable_u8_obs()        # (the teacher's full-grid image: 675 instead of 2 700 B)
         self.use_hip_graphs = mode in ("1", "2") and self.device.type == "cuda"
         self.graph_pytorch_nets = mode == "2"       # also capture rollouts whose policy runs as PyTorch modules
         self._graphs = {}
@@ -336,6 +336,7 @@ class AdversarialRunner:
         else:
             body(0, num_steps)
         agent.storage.step = 0
+        agent.storage.mark_obs_stale()
         self.ued_venv.raise_errors()
 
     def _grid_actor(self, agent):
@@ -363,9 +364,10 @@ class AdversarialRunner:
         for step in range(t0, t1):
             with torch.no_grad():
                 if grid_actor is not None:
+                    img = st.obs_u8["image"] if st.obs_u8 is not None else st._obs["image"]
                     value, action, log_dist, hxs = grid_actor.act(
-                        st.get_obs(step), st.recurrent_hidden_states[step], st.masks[step], first=step == 0,
-                        prev_image=st.obs["image"][step - 1] if step else None)
+                        st.rollout_obs(step), st.recurrent_hidden_states[step], st.masks[step], first=step == 0,
+                        prev_image=img[step - 1] if step else None)
                 else:
                     value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step),
                                                              st.masks[step])

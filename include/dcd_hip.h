@@ -389,7 +389,8 @@ int dcd_policy_features(const DcdStudentNet* net, const float* image, const floa
 int dcd_policy_features_u8(const DcdStudentNet* net, const uint8_t* image_u8, const uint8_t* dir_u8, const float* hc,
                            const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream);
 /* VecPreprocessImageWrapper._preprocess (obs_wrappers.py:88-115) for N stored student observations:
- * image_f32[n,c,vx,vy] = image_u8[n,vx,vy,c] / 10.0, dir_f32[n] = dir_u8[n] (dir pointers may both be NULL).  Used where
+ * image_f32[n,c,vx,vy] = image_u8[n,vx,vy,c] / 10.0, dir_f32[n] = dir_u8[n] (dir pointers may both be NULL; V up to the
+ * grid size: the teacher's full-grid observations convert the same way).  Used where
  * fp32 observations are consumed in bulk (the PPO batch, the truncated-observation value pass). */
 int dcd_obs_u8_to_f32(const uint8_t* image_u8, const uint8_t* dir_u8, float* image_f32, float* dir_f32, int64_t N, int32_t V,
                       void* stream);
@@ -400,6 +401,10 @@ int dcd_obs_u8_to_f32(const uint8_t* image_u8, const uint8_t* dir_u8, float* ima
 int dcd_policy_grid_features(const DcdStudentNet* net, const float* image, const float* scalar, const float* z,
                              int32_t z_dim, const float* hc, const float* masks, float* x, int32_t x_pitch, int32_t B,
                              void* stream);
+/* dcd_policy_grid_features on the raw full-grid encoding uint8[B,S,S,3] ([x][y][c]: the teacher's rollout buffer in u8 mode). */
+int dcd_policy_grid_features_u8(const DcdStudentNet* net, const uint8_t* image_u8, const float* scalar, const float* z,
+                                int32_t z_dim, const float* hc, const float* masks, float* x, int32_t x_pitch, int32_t B,
+                                void* stream);
 /* Head weights re-laid out for the kernel below (stacked + transposed first layers, padded second layers):
  * packed: float[dcd_policy_packed_heads_floats()]; call again whenever the optimiser has stepped. */
 int dcd_policy_packed_heads_floats(void);

@@ -68,18 +68,52 @@ def test_runner_rollouts_identical_with_u8_and_fp32_buffers(monkeypatch):
         st = runner.agents["agent"].storage
         assert (st.obs_u8 is not None) == (mode == "1")
         stats = runner.run()
+        assert (runner.agents["adversary_env"].storage.obs_u8 is not None) == (mode == "1")       # the teacher's full-grid image too
         got[mode] = ({n: {k: v.clone() for k, v in _storage_tensors(runner.agents[n].storage).items() if not k.startswith("_")}
-                      for n in ("agent", "adversary_agent")},
+                      for n in ("agent", "adversary_agent", "adversary_env")},
                      {k: stats[k] for k in ("agent_value_loss", "adversary_value_loss", "agent_pg_loss", "mean_env_return")},
-                     {k: v.clone() for k, v in st.obs.items()}, st.truncated_value_preds.clone())
+                     {k: v.clone() for k, v in st.obs.items()}, st.truncated_value_preds.clone(),
+                     {k: v.clone() for k, v in runner.agents["adversary_env"].storage.obs.items()})
         venv.close()
     a, b = got["1"], got["0"]
     assert (a[3] != got["1"][0]["agent"]["value_preds"]).any()          # truncated observations were evaluated
     assert torch.equal(a[3], b[3])
     for k in a[2]:
         assert torch.equal(a[2][k], b[2][k]), k                          # derived fp32 observations == engine-written ones
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), ("teacher", k)
     for n in a[0]:
         for k in a[0][n]:
             if k in b[0][n] and "obs" not in k:
                 assert torch.equal(a[0][n][k], b[0][n][k]), (n, k)
     assert a[1] == b[1]
+
+
+def test_grid_actor_on_raw_bytes_equals_grid_actor_on_fp32():
+    """The teacher's rollout-time policy step reading the raw full-grid bytes (dcd_policy_grid_features_u8; carried
+    projection with byte windows through the exact k/10 table) == the same step on the preprocessed fp32 image, bit for
+    bit, dense and carried, over a whole teacher episode."""
+    from dcd_hip.policy import GridActor
+    from tests.test_gpu_runner import build, make_args
+    runner, venv = build(make_args(ued_algo="paired", num_processes=48))
+    teacher = runner.agents["adversary_env"]
+    net, st = teacher.algo.actor_critic, teacher.storage
+    assert st.obs_u8 is not None
+    runner._teacher_rollout(teacher, runner.adversary_env_rollout_steps)
+    for carried in (False, True):
+        g32, g8 = GridActor(net, 48), GridActor(net, 48)
+        if carried:
+            g32.begin_episode(); g8.begin_episode()
+        for step in range(runner.adversary_env_rollout_steps):
+            hc, masks = st.recurrent_hidden_states[step], st.masks[step]
+            kw32 = dict(first=step == 0, prev_image=st.obs["image"][step - 1] if step else None) if carried else {}
+            kw8 = dict(first=step == 0, prev_image=st.obs_u8["image"][step - 1] if step else None) if carried else {}
+            with torch.no_grad():
+                r32 = g32.act(st.get_obs(step), hc, masks, deterministic=True, **kw32)
+                r8 = g8.act(st.rollout_obs(step), hc, masks, deterministic=True, **kw8)
+            assert st.rollout_obs(step)["image"].dtype == torch.uint8
+            if carried:
+                assert g32._incremental and g8._incremental
+            for x, y in zip((r32[0], r32[1], r32[2], r32[3][0], r32[3][1]), (r8[0], r8[1], r8[2], r8[3][0], r8[3][1])):
+                assert torch.equal(x, y), (carried, step)
+    venv.close()
