@@ -187,6 +187,7 @@ class AdversarialRunner:
                     "total_seeds_collected", "total_num_edits", "student_grad_updates", "latest_env_stats",
                     "level_store", "level_samplers"):
             setattr(self, key, sd.get(key))
+        self._table = None                                            # the device mirror of the (replaced) level store refills lazily
         if self.args.use_plr:
             if self.world_size > 1:                                   # checkpoint written by rank 0: re-attach the group
                 import torch.distributed as dist
@@ -274,6 +275,8 @@ class AdversarialRunner:
     def _update_plr_with_current_unseen_levels(self, parent_seeds=None):
         levels = self._get_active_levels()
         self.current_level_seeds = self.level_store.insert(levels, parent_seeds=parent_seeds)
+        if self.use_byte_encoding and self.device.type == "cuda":
+            self._mirror_new_levels(self.current_level_seeds, self.ued_venv.get_encodings_device())
         passable = self.venv.get_passable() if (self.args.log_plr_buffer_stats or self.args.reject_unsolvable_seeds) else None
         seeds, solvable = self.current_level_seeds, passable
         if self.args.reject_unsolvable_seeds:
@@ -288,6 +291,7 @@ class AdversarialRunner:
         for sampler in self.all_level_samplers:
             all_seeds.update([x for x in sampler.seeds if x >= 0])
         self.level_store.reconcile_seeds(all_seeds)
+        self._prune_level_rows()
 
     def _get_weighted_num_edits(self):
         sampler = self.all_level_samplers[0]
@@ -298,6 +302,65 @@ class AdversarialRunner:
 
     def _sample_replay_decision(self):
         return self._default_level_sampler.sample_replay_decision()
+
+    # ---- device mirror of the level store (byte-encoded levels) --------------------------------------------------
+    # A replay rollout resets envs to stored levels at every step (each finished episode, :551-558) and 4096 at its start;
+    # taking the 675-byte encodings from the host store, stacking and uploading them was 27 ms of a replay update's 140 ms
+    # of per-step host work.  The encodings of every seed in use stay in ONE device tensor; a reset sends row indices.
+    def _level_rows(self, seeds):
+        """Rows of `seeds` in the device level table (uploading the ones it does not hold yet, in one batch)."""
+        if getattr(self, "_table", None) is None:
+            S = self.venv.proto.size
+            self._table = torch.zeros((0, S, S, 3), dtype=torch.uint8, device=self.device)
+            self._row_of, self._free_rows = {}, []
+        row_of = self._row_of
+        missing = [s for s in dict.fromkeys(seeds) if s not in row_of]
+        if missing:
+            enc = np.stack([np.asarray(self.level_store.get_level(s), dtype=np.uint8).reshape(self._table.shape[1:]) for s in missing])
+            self._store_rows(missing, torch.from_numpy(enc).to(self.device))
+        return torch.tensor([row_of[s] for s in seeds], dtype=torch.int64, device=self.device)
+
+    def _store_rows(self, seeds, enc_dev):
+        """enc_dev [n,S,S,3] (device) are the levels of `seeds` (n distinct, not yet in the table)."""
+        n = len(seeds)
+        while len(self._free_rows) < n:                                   # grow geometrically
+            old = self._table.shape[0]
+            grow = max(1024, old, n)
+            self._table = torch.cat([self._table, torch.zeros((grow,) + tuple(self._table.shape[1:]), dtype=torch.uint8, device=self.device)])
+            self._free_rows.extend(range(old + grow - 1, old - 1, -1))
+        rows = [self._free_rows.pop() for _ in range(n)]
+        self._table[torch.tensor(rows, dtype=torch.int64, device=self.device)] = enc_dev
+        self._row_of.update(zip(seeds, rows))
+
+    def _mirror_new_levels(self, seeds, enc_dev):
+        """After level_store.insert: the levels just built are already on the device — keep them (first row per new seed)."""
+        if getattr(self, "_table", None) is None:
+            self._level_rows([])
+        first = {}
+        for i, s in enumerate(seeds):
+            if s not in self._row_of and s not in first:
+                first[s] = i
+        if first:
+            idx = torch.tensor(list(first.values()), dtype=torch.int64, device=self.device)
+            self._store_rows(list(first.keys()), enc_dev.index_select(0, idx))
+
+    def _prune_level_rows(self):
+        if getattr(self, "_table", None) is not None:
+            for s in [s for s in self._row_of if s not in self.level_store.seed2level]:
+                self._free_rows.append(self._row_of.pop(s))
+
+    def _reset_all_to_stored_levels(self, seeds):
+        """venv.reset_to_level_batch([level_store.get_level(s) for s in seeds]) (:457-465)."""
+        if self.use_byte_encoding and self.device.type == "cuda":
+            self._reset_to_stored_levels(list(seeds), None, self.venv.engine.student_buffers(u8=False))
+            self.ued_venv.raise_errors()
+        else:
+            self.ued_venv.reset_to_level_batch([self.level_store.get_level(seed) for seed in seeds])
+
+    def _reset_to_stored_levels(self, seeds, idx_dev=None, out=None):
+        """reset_to_level for stored seeds (all envs, or the envs `idx_dev`) straight from the device table."""
+        enc = self._table.index_select(0, self._level_rows(seeds)) if len(seeds) else None
+        return self.venv.engine.reset_to_encoding(enc, idx_dev, out)
 
     # ---- rollouts --------------------------------------------------------------------------------
     # Rollout steps per HIP graph.  A whole rollout is ONE graph: a fused 256-step student rollout is ~1.5k kernel nodes, a
@@ -390,14 +453,13 @@ class AdversarialRunner:
         seeds = level_sampler.sample_replay_levels(len(idx))            # a collective when sharded: never skipped
         if not idx:
             return
-        levels = [self.level_store.get_level(s) for s in seeds]
-        kind, a, b = self.venv._levels_to_device(levels)
         idx_dev = finished.to(torch.int32)
         u8 = st.obs_u8 is not None
         out = self.venv.engine.student_buffers(len(idx), u8=u8, f32=not u8)
-        if kind == "enc":
-            self.venv.engine.reset_to_encoding(a, idx_dev, out)
+        if self.use_byte_encoding:
+            self._reset_to_stored_levels(seeds, idx_dev, out)
         else:
+            kind, a, b = self.venv._levels_to_device([self.level_store.get_level(s) for s in seeds])
             self.venv.engine.reset_to_actions(a, b, idx_dev, out)
         if u8:
             st.obs_u8["image"][step + 1][finished] = out["image_u8"]
@@ -579,15 +641,13 @@ class AdversarialRunner:
         B = args.num_processes
         if is_env:
             if edit_level:
-                levels = [self.level_store.get_level(seed) for seed in fixed_seeds]
-                self.ued_venv.reset_to_level_batch(levels)
+                self._reset_all_to_stored_levels(fixed_seeds)
                 self.ued_venv.mutate_level(num_edits=num_edits)
                 self._update_plr_with_current_unseen_levels(parent_seeds=fixed_seeds)
                 return
             if level_replay:
                 self.current_level_seeds = level_sampler.sample_replay_levels(B)
-                levels = [self.level_store.get_level(seed) for seed in self.current_level_seeds]
-                self.ued_venv.reset_to_level_batch(levels)
+                self._reset_all_to_stored_levels(self.current_level_seeds)
                 return self.current_level_seeds
             if self.is_dr and not args.use_plr:
                 self.ued_venv.reset_random_device({})
