@@ -303,7 +303,8 @@ class RolloutStorage:
         return self.truncated_value_preds
 
     def _value_source(self, next_value):
-        self.value_preds[-1] = next_value
+        if next_value.data_ptr() != self.value_preds[-1].data_ptr():      # already in place (fused bootstrap value)
+            self.value_preds[-1] = next_value
         v = self._compute_truncated_value_preds() if self.use_proper_time_limits else self.value_preds
         if self.use_popart:                          # storage.py:247-249,269-270: every value prediction denormalised
             self.denorm_value_preds = self.model.popart.denormalize(v).contiguous()

@@ -145,37 +145,86 @@ double np_pairwise_sum(const double* a, long n) {
 
 extern "C" double dcd_np_sum(const double* a, int64_t n) { return np_pairwise_sum(a, (long)n); }
 
+// numpy's pairwise summation over elements PRODUCED ON THE FLY: gen(i0, m, buf) computes (and stores) elements
+// [i0, i0+m) into buf — the same additions in the same order as np_pairwise_sum over the finished array, one pass less.
+template <class Gen>
+static inline double pairwise_gen(Gen& gen, double* a, long i0, long n) {
+  if (n <= 128) {
+    gen(i0, n, a + i0);
+    return np_pairwise_sum(a + i0, n);                               // the block is in L1: the adds are all that is left
+  }
+  long n2 = n / 2;
+  n2 -= n2 % 8;
+  const double l = pairwise_gen(gen, a, i0, n2);
+  return l + pairwise_gen(gen, a, i0 + n2, n - n2);
+}
+
 // returns the number of draws performed (== n unless an unhandled case stopped the loop early).
-// target_clones: an AVX2 build of the elementwise passes where the host has it (no FMA contraction either way).
-extern "C" __attribute__((target_clones("avx2", "default")))
+// target_clones: AVX2 / AVX-512 builds of the elementwise passes where the host has them (no FMA contraction either way).
+// Three passes over the buffer per draw instead of eight: [age + mask + sum], [mix + sum], [normalise + running sum]; the
+// last one is bound by the dependent additions of the cumulative sum (4 cycles each), which the result depends on.
+extern "C" __attribute__((target_clones("avx512f", "avx2", "default")))
 int64_t dcd_sampler_draws(int64_t N, int64_t n, const double* w_scores, double c, double* staleness, const double* unseen_keep,
                           const double* uniforms, int32_t update_staleness, int64_t* out_idx) {
   if (N <= 0 || n <= 0 || !w_scores || !staleness || !unseen_keep || !uniforms || !out_idx) return 0;
   std::vector<double> sw_, w_, cdf_;
   try { sw_.resize((size_t)N); w_.resize((size_t)N); cdf_.resize((size_t)N); } catch (const std::exception&) { return 0; }   // caller continues in numpy
   double* __restrict__ sw = sw_.data(); double* __restrict__ w = w_.data(); double* __restrict__ cdf = cdf_.data();
+  double* __restrict__ st = staleness;
+  bool aging = false;                                                // staleness + 1 of the previous draw still to be applied
+  auto flush = [&]() { if (aging) { for (int64_t i = 0; i < N; ++i) st[i] = st[i] + 1; aging = false; } };
   for (int64_t k = 0; k < n; ++k) {
-    double smin = staleness[0];
-    for (int64_t i = 0; i < N; ++i) { sw[i] = staleness[i] * unseen_keep[i]; smin = staleness[i] < smin ? staleness[i] : smin; }
+    // pass 1: (staleness += 1 of the previous draw,) sw = staleness * unseen_keep, z = np.sum(sw), any staleness < 0
+    double smin = 0.;
+    const double inc = aging ? 1. : 0.;                              // x + 0. == x for every x >= 0 and for -1 + 1 (the chosen seed)
+    auto gen1 = [&](long i0, long m, double* __restrict__ out) {
+      double mn = smin;
+      for (long j = 0; j < m; ++j) {
+        const double s = st[i0 + j] + inc;
+        st[i0 + j] = s;
+        out[j] = s * unseen_keep[i0 + j];
+        mn = s < mn ? s : mn;
+      }
+      smin = mn;
+    };
+    const double z = pairwise_gen(gen1, sw, 0, (long)N);
+    aging = false;
     if (smin < 0) return k;
-    const double z = np_pairwise_sum(sw, (long)N);
     if (!(z > 0)) return k;
-    for (int64_t i = 0; i < N; ++i) { const double q = sw[i] / z; const double t = c * q; w[i] = w_scores[i] + t; }
-    const double total = np_pairwise_sum(w, (long)N);
+    // pass 2: w = w_scores + c * (sw / z), total = np.sum(w)
+    auto gen2 = [&](long i0, long m, double* __restrict__ out) {
+      for (long j = 0; j < m; ++j) { const double q = sw[i0 + j] / z; const double t = c * q; out[j] = w_scores[i0 + j] + t; }
+    };
+    const double total = pairwise_gen(gen2, w, 0, (long)N);
     if (!(total > 1e-8 || total < -1e-8)) return k;                  // np.isclose(total, 0): the uniform fallback stays in Python
-    if (total != 1.0) for (int64_t i = 0; i < N; ++i) w[i] = w[i] / total;
+    // pass 3: w /= total (unless total == 1), cdf = cumsum(w): blocks of quotients (vector) ahead of the dependent additions
     double run = 0., mn = w[0];
-    for (int64_t i = 0; i < N; ++i) { run += w[i]; cdf[i] = run; mn = w[i] < mn ? w[i] : mn; }
+    const bool norm = total != 1.0;
+    constexpr int64_t BK = 32;
+    auto quot = [&](int64_t i0) {                                     // block i0: quotients + running minimum (vector code)
+      const int64_t m = N - i0 < BK ? N - i0 : BK;
+      if (norm) for (int64_t j = 0; j < m; ++j) w[i0 + j] = w[i0 + j] / total;
+      double bm = mn;
+      for (int64_t j = 0; j < m; ++j) bm = w[i0 + j] < bm ? w[i0 + j] : bm;
+      mn = bm;
+    };
+    quot(0);
+    for (int64_t i0 = 0; i0 < N; i0 += BK) {                          // software pipeline: block i0+BK divides while block i0 adds
+      if (i0 + BK < N) quot(i0 + BK);
+      const int64_t m = N - i0 < BK ? N - i0 : BK;
+      for (int64_t j = 0; j < m; ++j) { run += w[i0 + j]; cdf[i0 + j] = run; }
+    }
     const double last = cdf[N - 1];
     if (!(last - 1.0 <= 1e-8 && 1.0 - last <= 1e-8) || mn < 0) return k;
     const double u = uniforms[k];
     int64_t lo = 0, hi = N;                                          // searchsorted(cdf / last, u, side='right')
     while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (cdf[mid] / last <= u) lo = mid + 1; else hi = mid; }
     out_idx[k] = lo;
-    if (update_staleness) {
-      for (int64_t i = 0; i < N; ++i) staleness[i] = staleness[i] + 1;
-      if (lo < N) staleness[lo] = 0;
+    if (update_staleness) {                                          // staleness + 1, chosen seed -> 0: applied inside the next pass 1
+      if (lo < N) st[lo] = -1.;
+      aging = true;
     }
   }
+  flush();
   return n;
 }

@@ -371,6 +371,167 @@ __global__ void __launch_bounds__(256) gather_sum_rows_kernel(const float* __res
   *o = w;
 }
 
+// ---- the teacher's carried input projection, device-resident (no host synchronisation, fixed shapes: graph-capturable) --------
+// A constructive teacher step changes at most ONE cell of the full-grid observation (adversarial.py:466-530: a wall on a
+// free cell, the goal, or the agent), i.e. at most nine of the P = (S-2)^2 conv positions see a different 3x3 window.
+// Per step:  xp[b] += sum over those positions p of (relu(conv)(new window) - relu(conv)(old window)) @ Wp[p],
+// Wp[p] = W_ih[:, f*P + p]^T [F, 4H].  The (env, position) rows are binned by POSITION so that one weight block serves a
+// whole tile of rows: bins are padded to DR-row tiles, the GEMM runs over a FIXED number of tiles (dcd_grid_delta_tiles)
+// whose weight block index comes from a device table, and unused tiles multiply garbage nobody reads.
+//   grid_changed_cell_kernel  one wave per env: the changed cell (or -1), error bit if more than one cell changed
+//   grid_bin_rank_kernel      one workgroup per position: members in env order -> rank within the bin, bin size
+//   grid_delta_rows_kernel    bin bases (prefix over padded sizes), feature-difference rows, (env, slot) -> row table,
+//                             tile -> position table
+// Ranks follow env order, so rows, sums and results do not depend on scheduling.
+constexpr int DR = 128;           // rows per GEMM tile (rocBLAS runs 128-row batches at twice the rate of 64-row ones)
+constexpr int DE = 8;             // envs per workgroup, grid_delta_rows_kernel
+constexpr int DMAXP = 256;        // (GMAXS - 2)^2 = 225 positions at most
+
+__global__ void __launch_bounds__(256) grid_changed_cell_kernel(const uint8_t* __restrict__ cur, const uint8_t* __restrict__ prev, long long prev_stride,
+                                                                int S, int B, int32_t* __restrict__ cell, int32_t* __restrict__ src,
+                                                                int32_t* __restrict__ err) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int NC = S * S;
+  const uint8_t* a = cur + (size_t)b * NC * 3;
+  const uint8_t* o = prev + (size_t)b * prev_stride;
+  int first = -1, n = 0;
+  for (int c0 = 0; c0 < NC; c0 += 64) {                                // wave-uniform trip count
+    const int c = c0 + lane;
+    bool ch = false;
+    if (c < NC) ch = a[c * 3] != o[c * 3] || a[c * 3 + 1] != o[c * 3 + 1] || a[c * 3 + 2] != o[c * 3 + 2];
+    const unsigned long long m = __ballot(ch);
+    if (m && first < 0) first = c0 + __ffsll((long long)m) - 1;
+    n += __popcll(m);
+  }
+  if (lane == 0) {
+    cell[b] = first;
+    if (n > 1) atomicOr(err, 1);
+  }
+  if (lane < 9) src[(size_t)b * 9 + lane] = -1;
+}
+
+// position p = (r, q) sees cell (cr, cq) iff r <= cr <= r+2 and q <= cq <= q+2; slot of the pair = (cr-r)*3 + (cq-q)
+__global__ void __launch_bounds__(256) grid_bin_rank_kernel(const int32_t* __restrict__ cell, int S, int B, int32_t* __restrict__ src,
+                                                            int32_t* __restrict__ count) {
+  __shared__ int s_part[256];
+  const int p = blockIdx.x, O = S - 2, r = p / O, q = p - r * O, tid = threadIdx.x;
+  const int per = (B + 255) / 256, b0 = tid * per, b1 = min(B, b0 + per);
+  int mine = 0;
+  for (int b = b0; b < b1; ++b) {
+    const int c = cell[b];
+    if (c >= 0) { const int cr = c / S, cq = c - cr * S; mine += (cr >= r && cr <= r + 2 && cq >= q && cq <= q + 2); }
+  }
+  s_part[tid] = mine;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {                                  // inclusive scan
+    const int v = tid >= d ? s_part[tid - d] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int rank = s_part[tid] - mine;
+  if (tid == 255) count[p] = s_part[255];
+  for (int b = b0; b < b1; ++b) {
+    const int c = cell[b];
+    if (c < 0) continue;
+    const int cr = c / S, cq = c - cr * S;
+    if (cr >= r && cr <= r + 2 && cq >= q && cq <= q + 2) src[(size_t)b * 9 + (cr - r) * 3 + (cq - q)] = rank++;
+  }
+}
+
+__global__ void __launch_bounds__(256) grid_delta_rows_kernel(DcdStudentNet n, const uint8_t* __restrict__ cur, const uint8_t* __restrict__ prev,
+                                                              long long prev_stride, const int32_t* __restrict__ cell,
+                                                              const int32_t* __restrict__ count, int32_t* __restrict__ src,
+                                                              float* __restrict__ rows, int32_t* __restrict__ tile_pos, int n_tiles,
+                                                              int B, int32_t* __restrict__ err) {
+  __shared__ float s_w[GMAXF * 27 + GMAXF];
+  __shared__ float s_new[DE][3][25], s_old[DE][3][25];                  // the 5 x 5 cells around each env's changed cell
+  __shared__ int s_base[DMAXP + 1], s_row[DE][9], s_cell[DE];
+  const int tid = threadIdx.x, S = n.V, O = S - 2, P = O * O, F = n.F, env0 = blockIdx.x * DE, ne = min(DE, B - env0);
+  if (tid < ne) s_cell[tid] = cell[env0 + tid];
+  for (int q = tid; q < F * 27; q += 256) s_w[q] = n.conv_w[q];
+  for (int q = tid; q < F; q += 256) s_w[GMAXF * 27 + q] = n.conv_b[q];
+  s_base[tid] = tid < P ? (count[tid] + DR - 1) / DR * DR : 0;           // padded bin sizes -> exclusive prefix
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int v = tid >= d ? s_base[tid - d] : 0;
+    __syncthreads();
+    s_base[tid] += v;
+    __syncthreads();
+  }
+  const int incl = s_base[tid];
+  __syncthreads();
+  s_base[tid + 1 <= DMAXP ? tid + 1 : DMAXP] = incl;                     // s_base[p] = rows before bin p (tid 255 -> slot 256)
+  if (tid == 0) s_base[0] = 0;
+  __syncthreads();
+  if (blockIdx.x == 0) {                                               // tile -> position table for the GEMM's weight blocks
+    if (tid == 0 && s_base[P] > n_tiles * DR) atomicOr(err, 2);
+    for (int t = tid; t < n_tiles; t += 256) {
+      int lo = 0, hi = P;                                              // last p with base[p] <= t*DR
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_base[mid] <= t * DR) lo = mid; else hi = mid; }
+      tile_pos[t] = lo;
+    }
+  }
+  // windows: thread -> (env e, channel c, neighbourhood cell (i, j)), cells outside the grid read as 0 (never used)
+  for (int w = tid; w < ne * 75; w += 256) {
+    const int e = w / 75, r75 = w - e * 75, c = r75 / 25, ij = r75 - c * 25, i = ij / 5, j = ij - i * 5;
+    const int cc = s_cell[e];
+    float vn = 0.f, vo = 0.f;
+    if (cc >= 0) {
+      const int cr = cc / S + i - 2, cq = cc % S + j - 2;
+      if (cr >= 0 && cr < S && cq >= 0 && cq < S) {
+        const size_t off = (size_t)(cr * S + cq) * 3 + c;
+        vn = dcd::div10f(cur[(size_t)(env0 + e) * S * S * 3 + off]);
+        vo = dcd::div10f(prev[(size_t)(env0 + e) * prev_stride + off]);
+      }
+    }
+    s_new[e][c][ij] = vn; s_old[e][c][ij] = vo;
+  }
+  if (tid < ne * 9) {                                                  // (env, slot) -> row of the binned operand
+    const int e = tid / 9, k = tid - e * 9, cc = s_cell[e];
+    int row = -1;
+    if (cc >= 0) {
+      const int r = cc / S - k / 3, q = cc % S - k % 3;                // slot k = (cr-r)*3 + (cq-q)
+      if (r >= 0 && r < O && q >= 0 && q < O) {
+        row = s_base[r * O + q] + src[(size_t)(env0 + e) * 9 + k];
+        if (row >= n_tiles * DR) row = -1;                             // cannot happen (error bit 2 above); never write outside
+      }
+    }
+    s_row[e][k] = row;
+    src[(size_t)(env0 + e) * 9 + k] = row;
+  }
+  __syncthreads();
+  // thread <-> filter f (its 27 weights in registers), the workgroup's 256 / FP2 pair lanes walk the (env, slot) pairs:
+  // a wave reads one pair's window values as LDS broadcasts and writes 64 consecutive floats of its row.  VALU-bound
+  // (36.8k rows x 128 filters x 54 FMAs at 4096 envs: ~30 us); fetching a pair's 54 window values with one LDS read and
+  // handing them round by v_readlane measured the same (the readlane takes the issue slot the LDS read freed).
+  const int FP2 = F <= 32 ? 32 : (F <= 64 ? 64 : 128), f = tid & (FP2 - 1), lanes = 256 / FP2;
+  if (f >= F) return;
+  float w[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) w[k] = s_w[f * 27 + k];
+  const float bias = s_w[GMAXF * 27 + f];
+  for (int pair = tid / FP2; pair < ne * 9; pair += lanes) {
+    const int e = pair / 9, k = pair - e * 9;
+    const int row = s_row[e][k];
+    if (row < 0) continue;
+    // position (r, q) = (cr - k/3, cq - k%3): its window cell (k1, k2) is neighbourhood cell (2 - k/3 + k1, 2 - k%3 + k2)
+    const int i0 = 2 - k / 3, j0 = 2 - k % 3;
+    float an = bias, ao = bias;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 3; ++k2) {
+          an = fmaf(w[c * 9 + k1 * 3 + k2], s_new[e][c][(i0 + k1) * 5 + j0 + k2], an);
+          ao = fmaf(w[c * 9 + k1 * 3 + k2], s_old[e][c][(i0 + k1) * 5 + j0 + k2], ao);
+        }
+    rows[(size_t)row * F + f] = fmaxf(an, 0.f) - fmaxf(ao, 0.f);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -508,5 +669,33 @@ int dcd_gather_sum_rows(const float* y, const int32_t* src, float* out, int32_t 
   return 0;
 }
 
+int dcd_grid_delta_tile_rows(void) { return DR; }
+
+int dcd_grid_delta_tiles(int32_t S, int32_t B) {
+  if (S < 3 || S > GMAXS || B <= 0) return 0;
+  const long long P = (long long)(S - 2) * (S - 2);
+  return (int)((9LL * B + P * (DR - 1) + DR - 1) / DR);
+}
+
+int dcd_grid_delta_rows(const DcdStudentNet* net, const uint8_t* image_u8, const uint8_t* prev_u8, int64_t prev_env_stride,
+                        int32_t* cell, int32_t* count, int32_t* src, float* rows, int32_t* tile_pos, int32_t n_tiles,
+                        int32_t* err, int32_t B, void* stream) {
+  if (!net || !image_u8 || !prev_u8 || !cell || !count || !src || !rows || !tile_pos || !err || B <= 0)
+    return dcd::fail("dcd_grid_delta_rows: NULL pointer or empty batch");
+  if (net->V < 3 || net->V > GMAXS || net->F < 1 || net->F > GMAXF || !net->conv_w || !net->conv_b)
+    return dcd::fail("dcd_grid_delta_rows: grid size must be 3..17, F <= 128, conv weights set");
+  if (n_tiles < dcd_grid_delta_tiles(net->V, B)) return dcd::fail("dcd_grid_delta_rows: n_tiles below dcd_grid_delta_tiles(S, B)");
+  const int S = net->V, P = (S - 2) * (S - 2);
+  if (prev_env_stride != 0 && prev_env_stride != (int64_t)S * S * 3)
+    return dcd::fail("dcd_grid_delta_rows: prev_env_stride must be 0 (one image for all envs) or S*S*3");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(grid_changed_cell_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, image_u8, prev_u8, (long long)prev_env_stride, S, B,
+                     cell, src, err);
+  hipLaunchKernelGGL(grid_bin_rank_kernel, dim3((unsigned)P), dim3(256), 0, st, (const int32_t*)cell, S, B, src, count);
+  hipLaunchKernelGGL(grid_delta_rows_kernel, dim3((unsigned)((B + DE - 1) / DE)), dim3(256), 0, st, *net, image_u8, prev_u8,
+                     (long long)prev_env_stride, (const int32_t*)cell, (const int32_t*)count, src, rows, tile_pos, n_tiles, B, err);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_grid_delta_rows: launch failed");
+  return 0;
+}
 
 }  // extern "C"

@@ -151,6 +151,22 @@ class StudentActor:
                       st.recurrent_hidden_states[step + 1], st.value_preds[step], st.actions[step], st.action_log_probs[step],
                       st.action_log_dist[step], deterministic=deterministic)
 
+    def value_storage(self, st, step):
+        """`agent.get_value(obs[step], h[step], masks[step])` (adversarial_runner.py:586-590: the bootstrap value of a
+        finished rollout) by the same three launches as a rollout step, written into value_preds[step]; the sampled
+        action and the next hidden state go to scratch.  Same value as the step kernels give during the rollout."""
+        if getattr(self, "_scratch", None) is None:
+            B, dev = self.B, self.device
+            self._scratch = (torch.empty((B, 2 * self.H), device=dev), torch.empty((B, 1), dtype=torch.int64, device=dev),
+                             torch.empty((B, 1), device=dev), torch.empty((B, self._dims["NA"]), device=dev))
+        hc, action, log_prob, log_dist = self._scratch
+        self.refresh()
+        self.counter = step
+        o = st.obs_u8 if st.obs_u8 is not None else st._obs
+        self.act_into(o["image"][step], o["direction"][step], st.recurrent_hidden_states[step], st.masks[step],
+                      hc, st.value_preds[step], action, log_prob, log_dist, deterministic=True)
+        return st.value_preds[step]
+
 
 _DIV10 = {}
 
@@ -237,7 +253,9 @@ class GridActor:
             torch.add(l.bias_ih_l0, l.bias_hh_l0, out=self.bias)
             F, G = self._dims["F"], 4 * self.H
             P = (self._dims["V"] - 2) ** 2
-            self.wp = l.weight_ih_l0[:, :F * P].view(G, F, P).permute(2, 1, 0).contiguous()      # [P, F, 4H]: per-position blocks
+            if getattr(self, "wp", None) is None:                  # persistent: captured graphs keep pointing at it
+                self.wp = torch.empty((P, F, G), device=self.w_t.device)
+            self.wp.copy_(l.weight_ih_l0[:, :F * P].view(G, F, P).permute(2, 1, 0))             # [P, F, 4H]: per-position blocks
         s = StudentNet()
         for name, p in zip(("conv_w", "conv_b", "embed_w", "embed_b"), self._params):
             setattr(s, name, ptr(p.detach(), torch.float32, name=name).value)
@@ -306,9 +324,71 @@ class GridActor:
                                         C.c_int32(kmax), C.c_int32(G), stream_ptr()))
         return True
 
+    # ---- the same, device-resident (raw u8 observations): no host synchronisation, fixed shapes, graph-capturable ---
+    def device_carry_supported(self, image):
+        return incremental_act_enabled() and image.dtype == torch.uint8 and image.dim() == 4 and image.shape[-1] == 3
+
+    def _device_buffers(self):
+        if getattr(self, "_d", None) is None:
+            L, dev, B, G, F = lib(), self.x.device, self.B, 4 * self.H, self._dims["F"]
+            S = self._dims["V"]
+            P = (S - 2) ** 2
+            Tt, R = L.dcd_grid_delta_tiles(S, B), L.dcd_grid_delta_tile_rows()
+            i32 = dict(dtype=torch.int32, device=dev)
+            self._d = dict(Tt=Tt, R=R, cell=torch.zeros(B, **i32), count=torch.zeros(P, **i32), src=torch.full((B, 9), -1, **i32),
+                           rows=torch.zeros((Tt * R, F), device=dev), tile=torch.zeros(Tt, **i32),
+                           wg=torch.empty((Tt, F, G), device=dev), y=torch.empty((Tt * R, G), device=dev),
+                           err=torch.zeros(1, **i32), xp=torch.empty((B, G), device=dev))
+        return self._d
+
+    def _carry_projection_device(self, image, prev_image):
+        """`_carry_projection` for raw u8 images with nothing read back: `dcd_grid_delta_rows` finds each env's changed
+        cell, bins the (env, conv position) pairs by position in env order and writes their feature differences as
+        fixed-height tiles; ONE batched GEMM over a fixed number of tiles multiplies each tile by its position's weight block
+        (gathered by the device-side tile table); dcd_gather_sum_rows adds an env's <= 9 rows in slot order.  The first
+        step takes env 0's image as every env's previous image (after the teacher's reset all grids are the same empty
+        room; a grid that differs from it in one cell is still exact).  More than one changed cell in a step sets an error
+        word that `check_carry_errors` turns into an exception."""
+        d, net, B, G = self._device_buffers(), self.net, self.B, 4 * self.H
+        S, F = self._dims["V"], self._dims["F"]
+        P = (S - 2) ** 2
+        L = lib()
+        if prev_image is None:
+            xp0 = net.image_conv(_u8_to_chw(image[:1])) @ self._lstm.weight_ih_l0[:, :F * P].t()
+            d["xp"].copy_(xp0.expand(B, G))
+            prev_image, stride = image[:1], 0
+        else:
+            stride = S * S * 3
+        self._xp_img = d["xp"]
+        check(L.dcd_grid_delta_rows(C.byref(self._struct), ptr(image, torch.uint8, B * S * S * 3, "image_u8"),
+                                    ptr(prev_image, torch.uint8, S * S * 3 * (B if stride else 1), "prev_u8"), C.c_int64(stride),
+                                    ptr(d["cell"], torch.int32), ptr(d["count"], torch.int32), ptr(d["src"], torch.int32),
+                                    ptr(d["rows"], torch.float32), ptr(d["tile"], torch.int32), C.c_int32(d["Tt"]),
+                                    ptr(d["err"], torch.int32), C.c_int32(B), stream_ptr()))
+        torch.index_select(self.wp, 0, d["tile"], out=d["wg"])
+        torch.bmm(d["rows"].view(d["Tt"], d["R"], F), d["wg"], out=d["y"].view(d["Tt"], d["R"], G))
+        check(L.dcd_gather_sum_rows(ptr(d["y"], torch.float32), ptr(d["src"], torch.int32), ptr(d["xp"], torch.float32), C.c_int32(B),
+                                    C.c_int32(9), C.c_int32(G), stream_ptr()))
+        return True
+
+    def check_carry_errors(self):
+        """Call after a rollout (it synchronises): raises if a step broke the carried projection's one-cell contract."""
+        d = getattr(self, "_d", None)
+        if d is None:
+            return
+        e = int(d["err"].item())
+        if e:
+            d["err"].zero_()
+            raise DcdHipError(f"carried teacher projection: error word {e} (1: more than one cell of an observation changed in "
+                              "one step, 2: tile table overflow) - the rollout's projections are invalid; DCD_INCREMENTAL_ACT=0 "
+                              "multiplies the dense operand instead")
+
     def act(self, obs, hc_in, masks, deterministic=False, prev_image=None, first=False):
         """`first` / `prev_image` (the previous step's image of the same episode) enable the carried projection
         (`begin_episode` must have been called); without them every step multiplies the dense operand."""
+        if (first or prev_image is not None) and getattr(self, "_incremental", False) and self.device_carry_supported(obs["image"]):
+            self._carry_projection_device(obs["image"], None if first else prev_image)
+            return self._act_carried(obs, hc_in, masks, deterministic)
         if (first or prev_image is not None) and getattr(self, "_incremental", False) and not torch.cuda.is_current_stream_capturing():
             self._incremental = self._carry_projection(obs["image"], None if first else prev_image)
             if self._incremental:

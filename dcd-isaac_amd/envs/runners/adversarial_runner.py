@@ -394,13 +394,22 @@ class AdversarialRunner:
 
     def _teacher_rollout(self, agent, num_steps):
         body = lambda t0, t1: self._teacher_rollout_body(agent, t0, t1)
-        if self.graph_pytorch_nets:
+        ga = self._grid_actor(agent) if self.is_discrete_adversary_env_actions else None
+        st = agent.storage
+        # the carried projection on raw u8 observations reads nothing back: the whole constructive episode is one graph
+        device_resident = (ga is not None and self.use_hip_graphs and st.obs_u8 is not None
+                           and ga.device_carry_supported(st.obs_u8["image"][0]))
+        if self.graph_pytorch_nets or device_resident:
+            if ga is not None:
+                ga.refresh()                                             # optimiser steps are picked up OUTSIDE the capture
             self._graphed(("teacher", id(agent), num_steps, bool(agent.actor_critic.random)), num_steps, body)
         else:
             body(0, num_steps)
         agent.storage.step = 0
         agent.storage.mark_obs_stale()
         self.ued_venv.raise_errors()
+        if ga is not None:
+            ga.check_carry_errors()
 
     def _grid_actor(self, agent):
         """dcd_hip.policy.GridActor for a recurrent teacher (features kernel + one stacked GEMM), or None."""
@@ -534,6 +543,16 @@ class AdversarialRunner:
             return None
         return fa
 
+    def _bootstrap_value(self, agent):
+        """The value of the observation after the last step (adversarial_runner.py:586-590), by the fused policy step
+        when the rollout used it (3 launches, no fp32 observation materialised), else by the PyTorch modules."""
+        st = agent.storage
+        fused = self._fused_actor(agent) if self.is_discrete_actions else None
+        if fused is not None and not st.use_popart:
+            return fused.value_storage(st, st.num_steps)
+        with torch.no_grad():
+            return agent.get_value(st.get_obs(-1), st.get_recurrent_hidden_state(-1), st.masks[-1]).detach()
+
     def _student_rollout_body(self, agent, num_steps, t0, t1, level_replay, level_sampler, rollout_info):
         args, st, venv = self.args, agent.storage, self.venv
         reset_random = self.is_dr and not args.use_plr
@@ -594,9 +613,7 @@ class AdversarialRunner:
         scans.rollout_return_stats_batch([(a.storage.ep_ret, a.storage.ep_info) + o for a, o in zip(agents, outs)])
         self._pair_cache = {id(a): {"stats": o} for a, o in zip(agents, outs)}
         if self.is_training:
-            with torch.no_grad():
-                nvs = [a.get_value(a.storage.get_obs(-1), a.storage.get_recurrent_hidden_state(-1), a.storage.masks[-1]).detach()
-                       for a in agents]
+            nvs = [self._bootstrap_value(a) for a in agents]
             type(agents[0].storage).compute_returns_batch([a.storage for a in agents], nvs, self.args.use_gae, self.args.gamma,
                                                           self.args.gae_lambda)
             for a in agents:
@@ -682,9 +699,7 @@ class AdversarialRunner:
         if update:
             st = agent.storage
             if not cache.get("returns"):
-                with torch.no_grad():
-                    next_value = agent.get_value(st.get_obs(-1), st.get_recurrent_hidden_state(-1), st.masks[-1]).detach()
-                st.compute_returns(next_value, args.use_gae, args.gamma, args.gae_lambda)
+                st.compute_returns(self._bootstrap_value(agent), args.use_gae, args.gamma, args.gae_lambda)
             if self.requires_batched_vloss:
                 clipped = not args.adv_use_popart and not args.adv_normalize_returns
                 rollout_info["batched_value_loss"] = st.get_batched_value_loss(

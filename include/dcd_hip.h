@@ -447,6 +447,25 @@ int dcd_lstm_seq_bwd_step(const float* act, const float* c_t, const float* c_pre
  * src int32[R,K] (negative = no term), terms added in k order; y float[*,G], out float[R,G], G a multiple of 4,
  * y / out 16-byte aligned. */
 int dcd_gather_sum_rows(const float* y, const int32_t* src, float* out, int32_t R, int32_t K, int32_t G, void* stream);
+/* The gather side of the same projection, device-resident (nothing read back, fixed shapes: the teacher's rollout is a
+ * HIP graph).  A constructive teacher step changes at most one cell of the observation (adversarial.py:466-530), so at most
+ * nine conv positions per env see a different window.  For image_u8 / prev_u8 uint8[B,S,S,3] (prev_env_stride = S*S*3; 0:
+ * prev_u8 is ONE image taken as every env's previous one) the call writes
+ *   cell  int32[B]      the changed cell x*S+y, or -1;
+ *   count int32[(S-2)^2] (env, position) pairs per conv position;
+ *   src   int32[B,9]    row of pair (env, slot) in `rows`, -1 if none: pairs are binned by position, bins padded to R-row
+ *                       tiles, rows inside a bin in env order (so no result depends on scheduling);
+ *   rows  float[n_tiles*R, F]   relu(conv)(new window) - relu(conv)(old window) of every pair (other rows: not written);
+ *   tile_pos int32[n_tiles]     the position whose weight block multiplies tile t (tiles past the last bin: any valid index);
+ *   err   int32[1]      |= 1 if some env changed in more than one cell, |= 2 on tile overflow (cannot happen with
+ *                       n_tiles >= dcd_grid_delta_tiles(S, B) = ceil((9 B + (R-1) (S-2)^2) / R), R = dcd_grid_delta_tile_rows()).
+ * The caller then runs Y[t] = rows[t] @ Wp[tile_pos[t]] for all tiles and dcd_gather_sum_rows(Y, src, xp, B, 9, 4H).
+ * Only V (= S), F, conv_w, conv_b of `net` are read. */
+int dcd_grid_delta_tile_rows(void);
+int dcd_grid_delta_tiles(int32_t S, int32_t B);
+int dcd_grid_delta_rows(const DcdStudentNet* net, const uint8_t* image_u8, const uint8_t* prev_u8, int64_t prev_env_stride,
+                        int32_t* cell, int32_t* count, int32_t* src, float* rows, int32_t* tile_pos, int32_t n_tiles,
+                        int32_t* err, int32_t B, void* stream);
 
 /* ---- logging statistics (HOST pointers — the only entry point that is not a device call) ------------------ */
 /* RolloutStorage.get_action_complexity / get_batched_action_complexity (algos/storage.py:329-369): LZ76 phrase

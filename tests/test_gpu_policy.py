@@ -138,6 +138,39 @@ def test_act_storage_fills_the_reference_fields_and_tracks_optimizer_steps():
     assert (st.recurrent_hidden_states[2] - torch.cat([h2, c2], -1)).abs().max().item() <= ATOL
 
 
+@pytest.mark.parametrize("u8", [False, True])
+def test_value_storage_is_get_value_of_the_last_observation(u8):
+    """The bootstrap value after a rollout (adversarial_runner.py:586-590) by the fused launches: equals the module's
+    get_value on obs[T], leaves every rollout field of the storage alone."""
+    from algos import RolloutStorage
+    from envs import spaces
+    from dcd_hip.policy import StudentActor
+    B, T = 96, 3
+    net = _net(8)
+    obs = {"image": spaces.Box(0, 255, (3, 5, 5), "uint8"), "direction": spaces.Box(0, 3, (1,), "uint8")}
+    st = RolloutStorage(net, T, B, obs, spaces.Discrete(7), 256, recurrent_arch="lstm", use_proper_time_limits=True, device=DEV)
+    image, direction, hc, masks = _inputs(B, 4)
+    if u8:
+        st.enable_u8_obs()
+        st.obs_u8["image"][T].copy_((image * 10).round().permute(0, 2, 3, 1).to(torch.uint8))
+        st.obs_u8["direction"][T].copy_(direction.view(-1).to(torch.uint8))
+        st.mark_obs_stale()
+    else:
+        st.obs["image"][T].copy_(image); st.obs["direction"][T].copy_(direction)
+    st.recurrent_hidden_states[T].copy_(hc); st.masks[T].copy_(masks)
+    before = {k: getattr(st, k).clone() for k in ("actions", "action_log_probs", "action_log_dist", "recurrent_hidden_states")}
+    fa = StudentActor.try_create(net, B, seed=1)
+    v = fa.value_storage(st, T)
+    with torch.no_grad():
+        want = net.get_value(st.get_obs(-1), st.get_recurrent_hidden_state(-1), st.masks[-1])
+    assert v.data_ptr() == st.value_preds[-1].data_ptr()
+    assert (st.value_preds[-1] - want).abs().max().item() <= ATOL
+    for k, b in before.items():
+        assert torch.equal(getattr(st, k), b), k
+    st.compute_returns(v, True, 0.995, 0.95)                         # value already in place: no copy onto itself
+    assert torch.isfinite(st.returns).all()
+
+
 def test_unsupported_networks_fall_back_to_the_pytorch_modules():
     from envs import spaces
     from models import MultigridNetwork
@@ -349,4 +382,85 @@ def test_grid_actor_carried_projection_matches_dense_operand(monkeypatch):
     g0 = GridActor(net, 40)
     g0.begin_episode()
     assert not g0._incremental
+    venv.close()
+
+
+@pytest.mark.parametrize("B", [40, 333])
+def test_grid_actor_device_carried_projection_matches_dense_operand(B):
+    """The device-resident carried projection (dcd_grid_delta_rows + tiled batched GEMM + dcd_gather_sum_rows, raw u8
+    observations, nothing read back) against the dense operand over a real 27-step teacher episode: value, logits, (h', c')
+    within 2e-5 of scale at every step; the (env, slot) -> row table is a bijection onto the bins in env order; a step
+    that changes two cells raises through check_carry_errors; a first frame differing in ONE cell stays exact."""
+    from dcd_hip import DcdHipError
+    from dcd_hip.policy import GridActor
+    from tests.test_gpu_runner import build, make_args
+    args = make_args(ued_algo="paired", num_processes=B)
+    runner, venv = build(args)
+    teacher = runner.agents["adversary_env"]
+    net, st = teacher.algo.actor_critic, teacher.storage
+    assert st.obs_u8 is not None                                       # u8 rollout buffers are the default
+    T = runner.adversary_env_rollout_steps
+    runner._teacher_rollout(teacher, T)
+    img8 = st.obs_u8["image"]
+    ga, gd = GridActor(net, B), GridActor(net, B)
+    ga.begin_episode()
+    for step in range(T):
+        obs, hc, masks = st.rollout_obs(step), st.recurrent_hidden_states[step], st.masks[step]
+        assert ga.device_carry_supported(obs["image"])
+        with torch.no_grad():
+            v0, a0, l0, (h0, c0) = gd.act(obs, hc, masks, deterministic=True)
+            v1, a1, l1, (h1, c1) = ga.act(obs, hc, masks, deterministic=True, first=step == 0,
+                                          prev_image=img8[step - 1] if step else None)
+        for n, a, b in (("value", v0, v1), ("logits", l0, l1), ("h", h0, h1), ("c", c0, c1)):
+            err = (a - b).abs().max().item() / max(a.abs().max().item(), 1.0)
+            assert err <= 2e-5, (step, n, err)
+        top2 = l0.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert torch.equal(a0[clear], a1[clear])
+        # the binning: rows of (env, slot) pairs are distinct, lie in their position's bin, ranks follow env order
+        d = ga._d
+        cell, src, count = d["cell"].cpu().numpy(), d["src"].cpu().numpy(), d["count"].cpu().numpy()
+        tile = d["tile"].cpu().numpy()
+        changed = (img8[step] != (img8[step - 1] if step else img8[step][:1])).any(-1).flatten(1).cpu().numpy()
+        assert ((cell >= 0) == changed.any(1)).all() and (changed.sum(1) <= 1).all()
+        R = d["R"]
+        base = np.concatenate([[0], np.cumsum((count + R - 1) // R * R)])
+        rows = src[src >= 0]
+        assert len(np.unique(rows)) == len(rows) == count.sum()
+        for b in range(B):
+            for k in range(9):
+                if src[b, k] >= 0:
+                    cr, cq = divmod(int(cell[b]), 15)
+                    p = (cr - k // 3) * 13 + (cq - k % 3)
+                    assert base[p] <= src[b, k] < base[p] + count[p] and tile[src[b, k] // R] == p
+        last = {}
+        for b in range(B):                                            # env order within a bin
+            for k in range(9):
+                if src[b, k] >= 0:
+                    p = int(tile[src[b, k] // R])
+                    assert src[b, k] == base[p] + last.get(p, 0)
+                    last[p] = last.get(p, 0) + 1
+    ga.check_carry_errors()
+    # two changed cells in one step: error word -> exception
+    g2 = GridActor(net, B)
+    g2.begin_episode()
+    two = img8[0].clone()
+    two[1, 3, 3, 0] = 2
+    two[1, 7, 9, 0] = 2
+    obs0 = dict(st.rollout_obs(0))
+    with torch.no_grad():
+        g2.act(obs0, st.recurrent_hidden_states[0], st.masks[0], deterministic=True, first=True)
+        g2.act(dict(obs0, image=two), st.recurrent_hidden_states[0], st.masks[0], deterministic=True, prev_image=img8[0])
+    with pytest.raises(DcdHipError):
+        g2.check_carry_errors()
+    # a first frame that differs from env 0's in one cell is carried exactly
+    g1 = GridActor(net, B)
+    g1.begin_episode()
+    one = img8[0].clone()
+    one[2, 4, 6, 0] = 2
+    with torch.no_grad():
+        v1 = g1.act(dict(obs0, image=one), st.recurrent_hidden_states[0], st.masks[0], deterministic=True, first=True)[0]
+        v0 = gd.act(dict(obs0, image=one), st.recurrent_hidden_states[0], st.masks[0], deterministic=True)[0]
+    g1.check_carry_errors()
+    assert (v0 - v1).abs().max().item() <= 2e-5 * max(v0.abs().max().item(), 1.0)
     venv.close()

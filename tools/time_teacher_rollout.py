@@ -14,7 +14,8 @@ seed(1)
 venv, ued = create_parallel_env(args, device="cuda:0")
 agent = make_agent("agent", venv, args, "cuda:0"); teacher = make_agent("adversary_env", venv, args, "cuda:0")
 runner = AdversarialRunner(args=args, venv=venv, agent=agent, ued_venv=ued, adversary_env=teacher, train=True, device="cuda:0")
-runner._teacher_rollout(teacher, 27); torch.cuda.synchronize()
+for _ in range(3): runner._teacher_rollout(teacher, 27)          # eager warm-up, capture, first replay
+torch.cuda.synchronize()
 t = time.perf_counter()
-for _ in range(3): runner._teacher_rollout(teacher, 27)
-torch.cuda.synchronize(); print("teacher rollout ms", (time.perf_counter() - t) / 3 * 1e3)
+for _ in range(10): runner._teacher_rollout(teacher, 27)
+torch.cuda.synchronize(); print("teacher rollout ms", (time.perf_counter() - t) / 10 * 1e3)
