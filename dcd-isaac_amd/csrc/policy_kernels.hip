@@ -34,10 +34,23 @@ constexpr int MAXV = 7, MAXF = 32, MAXH = 256, MAXA = 16;
 // U8: the observation arrives as the env wrote it — raw encoding bytes [vx][vy][c] and a direction byte (RolloutStorage
 // in u8 mode: 76 instead of 304 bytes per env-step through HBM) — and VecPreprocessImageWrapper's /10 + HWC->CHW
 // (obs_wrappers.py:88-115) happens while the image is staged into LDS: dcd::div10f(k) is the exact fp32 of k / 10.0.
+// A launch serves up to two networks (PAIRED: protagonist and antagonist act on their own copies of the levels at the same
+// step): blockIdx.y picks the set — own parameters, inputs and operand rows; the launch is latency-bound, the second
+// network's workgroups ride along (9.3 us for one, see DESIGN.md §3 for both).
+struct FeatSets {
+  DcdStudentNet n[2];
+  const float* image[2]; const float* direction[2]; const float* hc[2]; const float* masks[2]; float* x[2];
+};
+
 template <int VV, int FF, int EE, int HH, bool U8 = false>
-__global__ void __launch_bounds__(PB) policy_features_kernel(DcdStudentNet n, const float* __restrict__ image,
-                                                             const float* __restrict__ direction, const float* __restrict__ hc,
-                                                             const float* __restrict__ masks, float* __restrict__ x, int KP, int B) {
+__global__ void __launch_bounds__(PB) policy_features_kernel(FeatSets S, int KP, int B) {
+  const int set = blockIdx.y;
+  const DcdStudentNet n = S.n[set];
+  const float* __restrict__ image = S.image[set];
+  const float* __restrict__ direction = S.direction[set];
+  const float* __restrict__ hc = S.hc[set];
+  const float* __restrict__ masks = S.masks[set];
+  float* __restrict__ x = S.x[set];
   __shared__ float s_img[FE][3 * MAXV * MAXV];
   __shared__ float s_w[MAXF * 27 + MAXF];
   __shared__ float s_emb[FE][16];
@@ -199,8 +212,13 @@ __global__ void __launch_bounds__(PB) heads_pack_kernel(DcdStudentNet n, float* 
 // Workgroup = CW waves x EW envs.  Cell: lane l owns hidden units l, l+64, l+128, l+192 of each of its wave's envs.
 // Heads layer 1: lane l = stacked unit l, the wave's envs advance together (one weight read feeds EW FMAs, their h
 // values come as one LDS broadcast).  Layer 2, log-softmax and sampling: 16 lanes per env.
+struct CellSets { DcdStudentNet n[2]; const float* packed[2]; CellArgs a[2]; };
+
 template <int H>
-__global__ void __launch_bounds__(CB) policy_cell_heads_kernel(DcdStudentNet n, const float* __restrict__ packed, CellArgs a) {
+__global__ void __launch_bounds__(CB) policy_cell_heads_kernel(CellSets S) {
+  const DcdStudentNet n = S.n[blockIdx.y];
+  const float* __restrict__ packed = S.packed[blockIdx.y];
+  const CellArgs a = S.a[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_pk = smem;                               // PK_FLOATS
   float* s_h = s_pk + PK_FLOATS;                    // [CW waves][H][EW envs]
@@ -444,7 +462,7 @@ __global__ void __launch_bounds__(256) grid_delta_rows_kernel(DcdStudentNet n, c
                                                               long long prev_stride, const int32_t* __restrict__ cell,
                                                               const int32_t* __restrict__ count, int32_t* __restrict__ src,
                                                               float* __restrict__ rows, int32_t* __restrict__ tile_pos, int n_tiles,
-                                                              int B, int32_t* __restrict__ err) {
+                                                              int32_t* __restrict__ n_used, int B, int32_t* __restrict__ err) {
   __shared__ float s_w[GMAXF * 27 + GMAXF];
   __shared__ float s_new[DE][3][25], s_old[DE][3][25];                  // the 5 x 5 cells around each env's changed cell
   __shared__ int s_base[DMAXP + 1], s_row[DE][9], s_cell[DE];
@@ -467,6 +485,7 @@ __global__ void __launch_bounds__(256) grid_delta_rows_kernel(DcdStudentNet n, c
   __syncthreads();
   if (blockIdx.x == 0) {                                               // tile -> position table for the GEMM's weight blocks
     if (tid == 0 && s_base[P] > n_tiles * DR) atomicOr(err, 2);
+    if (tid == 0) *n_used = min(s_base[P] / DR, n_tiles);
     for (int t = tid; t < n_tiles; t += 256) {
       int lo = 0, hi = P;                                              // last p with base[p] <= t*DR
       while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_base[mid] <= t * DR) lo = mid; else hi = mid; }
@@ -532,6 +551,85 @@ __global__ void __launch_bounds__(256) grid_delta_rows_kernel(DcdStudentNet n, c
   }
 }
 
+// ---- Y[t] = rows[t] @ Wp[tile_pos[t]]: the tiled product of the carried projection, fp32 MFMA ------------------------
+// One workgroup = one 128 x 128 block of Y: tile t (DR = 128 binned rows, K = F <= 128 features) x column block nb of the
+// position's weight block Wp[p] [F, G].  The whole K extent sits in LDS at once — A 128 x F (pitch 132: float4 stores,
+// 4-way conflicts on the fragment reads, which are 1/12 of the MFMA time), B F x 128 — so there is no K loop to
+// pipeline: load, barrier, 64 k-steps of v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain per element), store.
+// 4 waves as 2 x 2, each 64 x 64 = four 32 x 32 accumulators (4 independent MFMAs per 4 LDS reads).  Tiles past the
+// last bin (n_used, written by grid_delta_rows_kernel) exit at once: the padding of the fixed-shape launch costs nothing.
+// Replaces {index_select of 456 weight blocks (234 MB) + rocBLAS batched GEMM}: 308 -> see DESIGN.md §3.
+constexpr int GA_P = 132;          // LDS pitch of the A tile (floats)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int FF>                      // FF = 128: the teacher's filter count, loads fully unrolled; 0: runtime F
+__global__ void __launch_bounds__(256) grid_tile_gemm_kernel(const float* __restrict__ rows, const float* __restrict__ wp,
+                                                             const int32_t* __restrict__ tile_pos, const int32_t* __restrict__ n_used,
+                                                             float* __restrict__ y, int F_in, int G) {
+  const int F = FF ? FF : F_in;
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  float* As = gsm;                       // [DR][GA_P]
+  float* Bs = gsm + DR * GA_P;           // [F][128]
+  const int nbk = G / 128, t = blockIdx.x / nbk, nb = blockIdx.x - t * nbk, tid = threadIdx.x;
+  if (t >= *n_used) return;              // workgroup-uniform
+  const int p = tile_pos[t];
+  const float* a = rows + (size_t)t * DR * F;
+  const float* b = wp + (size_t)p * F * G + nb * 128;
+  const int F4 = F / 4;
+  if (FF == 128) {
+    // every global load of the workgroup in flight before the first LDS store: ONE memory round trip for the 128 KB of
+    // operands (the load -> store loop below waited 32 times: 255 us per step against 110)
+    float4 ra[16], rb[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ra[i] = reinterpret_cast<const float4*>(a)[i * 256 + tid];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int q = i * 256 + tid; rb[i] = *reinterpret_cast<const float4*>(b + (size_t)(q >> 5) * G + (q & 31) * 4); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int q = i * 256 + tid; *reinterpret_cast<float4*>(As + (q >> 5) * GA_P + (q & 31) * 4) = ra[i]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int q = i * 256 + tid; *reinterpret_cast<float4*>(Bs + (q >> 5) * 128 + (q & 31) * 4) = rb[i]; }
+  } else {
+    for (int q = tid; q < DR * F4; q += 256) {                         // A: rows contiguous in k
+      const int r = q / F4, k4 = q - r * F4;
+      *reinterpret_cast<float4*>(As + r * GA_P + k4 * 4) = reinterpret_cast<const float4*>(a)[q];
+    }
+    for (int q = tid; q < F * 32; q += 256) {                          // B: 128 columns of row k
+      const int k = q >> 5, c4 = q & 31;
+      *reinterpret_cast<float4*>(Bs + k * 128 + c4 * 4) = *reinterpret_cast<const float4*>(b + (size_t)k * G + c4 * 4);
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const float* a0 = As + (wm * 64 + li) * GA_P + lk;                   // A[i = li][k = k0 + lk]
+  const float* b0 = Bs + lk * 128 + wn * 64 + li;                      // B[k = k0 + lk][j = li]
+  for (int k0 = 0; k0 < F; k0 += 2) {
+    const float av0 = a0[k0], av1 = a0[32 * GA_P + k0];
+    const float bv0 = b0[k0 * 128], bv1 = b0[k0 * 128 + 32];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0, bv1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1, bv1, acc[1][1], 0, 0, 0);
+  }
+  // C/D map of the 32 x 32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  float* yo = y + ((size_t)t * DR + wm * 64) * G + nb * 128 + wn * 64 + li;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        yo[(size_t)row * G + j * 32] = acc[i][j][r];
+      }
+}
+
 }  // namespace
 
 extern "C" {
@@ -554,10 +652,12 @@ int dcd_policy_features(const DcdStudentNet* net, const float* image, const floa
   if (x_pitch < dcd_policy_input_width(net)) return dcd::fail("dcd_policy_features: x_pitch %d < K", x_pitch);
   if (!image || !direction || !hc || !masks || !x || B <= 0) return dcd::fail("dcd_policy_features: NULL pointer or B <= 0");
   const dim3 grid((B + FE - 1) / FE), block(PB);
+  FeatSets S{};
+  S.n[0] = *net; S.image[0] = image; S.direction[0] = direction; S.hc[0] = hc; S.masks[0] = masks; S.x[0] = x;
   if (net->V == 5 && net->F == 16 && net->E == 5 && net->H == 256)
-    hipLaunchKernelGGL((policy_features_kernel<5, 16, 5, 256>), grid, block, 0, (hipStream_t)stream, *net, image, direction, hc, masks, x, x_pitch, B);
+    hipLaunchKernelGGL((policy_features_kernel<5, 16, 5, 256>), grid, block, 0, (hipStream_t)stream, S, x_pitch, B);
   else
-    hipLaunchKernelGGL((policy_features_kernel<0, 0, 0, 0>), grid, block, 0, (hipStream_t)stream, *net, image, direction, hc, masks, x, x_pitch, B);
+    hipLaunchKernelGGL((policy_features_kernel<0, 0, 0, 0>), grid, block, 0, (hipStream_t)stream, S, x_pitch, B);
   if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_features: launch failed");
   return 0;
 }
@@ -594,19 +694,40 @@ int dcd_policy_pack_heads(const DcdStudentNet* net, float* packed, void* stream)
   return 0;
 }
 
+// one or two agents per launch (a1 may be NULL); the two networks must have one geometry
+static int features_u8_sets(const DcdPolicyAgent* a0, const DcdPolicyAgent* a1, int32_t x_pitch, int32_t B, void* stream, const char* who) {
+  FeatSets S{};
+  const DcdPolicyAgent* as[2] = {a0, a1};
+  const int ns = a1 ? 2 : 1;
+  for (int k = 0; k < ns; ++k) {
+    const DcdPolicyAgent* a = as[k];
+    if (check_net(a->net)) return 1;
+    if (x_pitch < dcd_policy_input_width(a->net)) return dcd::fail("%s: x_pitch %d < K", who, x_pitch);
+    if (!a->image_u8 || !a->dir_u8 || !a->hc_in || !a->masks || !a->x || B <= 0) return dcd::fail("%s: NULL pointer or B <= 0", who);
+    S.n[k] = *a->net; S.image[k] = reinterpret_cast<const float*>(a->image_u8); S.direction[k] = reinterpret_cast<const float*>(a->dir_u8);
+    S.hc[k] = a->hc_in; S.masks[k] = a->masks; S.x[k] = a->x;
+  }
+  const DcdStudentNet* n0 = a0->net;
+  if (a1 && (a1->net->V != n0->V || a1->net->F != n0->F || a1->net->E != n0->E || a1->net->H != n0->H || a1->net->D != n0->D))
+    return dcd::fail("%s: the two networks differ in geometry", who);
+  const dim3 grid((B + FE - 1) / FE, ns), block(PB);
+  if (n0->V == 5 && n0->F == 16 && n0->E == 5 && n0->H == 256)
+    hipLaunchKernelGGL((policy_features_kernel<5, 16, 5, 256, true>), grid, block, 0, (hipStream_t)stream, S, x_pitch, B);
+  else
+    hipLaunchKernelGGL((policy_features_kernel<0, 0, 0, 0, true>), grid, block, 0, (hipStream_t)stream, S, x_pitch, B);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("%s: launch failed", who);
+  return 0;
+}
+
 int dcd_policy_features_u8(const DcdStudentNet* net, const uint8_t* image_u8, const uint8_t* dir_u8, const float* hc, const float* masks,
                            float* x, int32_t x_pitch, int32_t B, void* stream) {
-  if (check_net(net)) return 1;
-  if (x_pitch < dcd_policy_input_width(net)) return dcd::fail("dcd_policy_features_u8: x_pitch %d < K", x_pitch);
-  if (!image_u8 || !dir_u8 || !hc || !masks || !x || B <= 0) return dcd::fail("dcd_policy_features_u8: NULL pointer or B <= 0");
-  const dim3 grid((B + FE - 1) / FE), block(PB);
-  const float* img = reinterpret_cast<const float*>(image_u8); const float* dir = reinterpret_cast<const float*>(dir_u8);
-  if (net->V == 5 && net->F == 16 && net->E == 5 && net->H == 256)
-    hipLaunchKernelGGL((policy_features_kernel<5, 16, 5, 256, true>), grid, block, 0, (hipStream_t)stream, *net, img, dir, hc, masks, x, x_pitch, B);
-  else
-    hipLaunchKernelGGL((policy_features_kernel<0, 0, 0, 0, true>), grid, block, 0, (hipStream_t)stream, *net, img, dir, hc, masks, x, x_pitch, B);
-  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_features_u8: launch failed");
-  return 0;
+  const DcdPolicyAgent a{net, nullptr, image_u8, dir_u8, hc, masks, x};
+  return features_u8_sets(&a, nullptr, x_pitch, B, stream, "dcd_policy_features_u8");
+}
+
+int dcd_policy_features_u8_pair(const DcdPolicyAgent* a0, const DcdPolicyAgent* a1, int32_t x_pitch, int32_t B, void* stream) {
+  if (!a0 || !a1) return dcd::fail("dcd_policy_features_u8_pair: NULL agent");
+  return features_u8_sets(a0, a1, x_pitch, B, stream, "dcd_policy_features_u8_pair");
 }
 
 int dcd_obs_u8_to_f32(const uint8_t* image_u8, const uint8_t* dir_u8, float* image_f32, float* dir_f32, int64_t N, int32_t V, void* stream) {
@@ -619,25 +740,45 @@ int dcd_obs_u8_to_f32(const uint8_t* image_u8, const uint8_t* dir_u8, float* ima
   return 0;
 }
 
-int dcd_policy_cell_heads(const DcdStudentNet* net, const float* packed, const float* gates, const float* hc_in, const float* masks, float* hc_out,
-                          float* value, int64_t* action, float* action_log_prob, float* action_log_dist, float* u_out,
-                          uint32_t seed, uint32_t counter, const uint32_t* counter_base, int64_t env_index_base, int32_t deterministic, int32_t B, void* stream) {
-  if (check_net(net)) return 1;
-  if (!packed || !gates || !hc_in || !masks || !hc_out || !value || !action || !action_log_prob || !action_log_dist || B <= 0)
-    return dcd::fail("dcd_policy_cell_heads: NULL pointer or B <= 0");
-  CellArgs a{gates, hc_in, masks, hc_out, value, action, action_log_prob, action_log_dist, u_out, seed, counter, counter_base, env_index_base,
-             deterministic, B};
+static int cell_heads_sets(const DcdPolicyAgent* a0, const DcdPolicyAgent* a1, int32_t B, void* stream, const char* who) {
+  CellSets S{};
+  const DcdPolicyAgent* as[2] = {a0, a1};
+  const int ns = a1 ? 2 : 1;
+  for (int k = 0; k < ns; ++k) {
+    const DcdPolicyAgent* a = as[k];
+    if (check_net(a->net)) return 1;
+    if (!a->packed || !a->gates || !a->hc_in || !a->masks || !a->hc_out || !a->value || !a->action || !a->log_prob || !a->log_dist || B <= 0)
+      return dcd::fail("%s: NULL pointer or B <= 0", who);
+    S.n[k] = *a->net; S.packed[k] = a->packed;
+    S.a[k] = CellArgs{a->gates, a->hc_in, a->masks, a->hc_out, a->value, a->action, a->log_prob, a->log_dist, a->u_out, a->seed, a->counter,
+                      a->counter_base, a->env_index_base, a->deterministic, B};
+  }
   const size_t lds = sizeof(float) * (PK_FLOATS + CW * MAXH * EW + CW * EW * 64);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&policy_cell_heads_kernel<MAXH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
-      return dcd::fail("dcd_policy_cell_heads: cannot reserve %zu bytes of LDS", lds);
+      return dcd::fail("%s: cannot reserve %zu bytes of LDS", who, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(policy_cell_heads_kernel<MAXH>, dim3((B + HE - 1) / HE), dim3(CB), lds, (hipStream_t)stream, *net, packed, a);
-  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_cell_heads: launch failed");
+  hipLaunchKernelGGL(policy_cell_heads_kernel<MAXH>, dim3((B + HE - 1) / HE, ns), dim3(CB), lds, (hipStream_t)stream, S);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("%s: launch failed", who);
   return 0;
+}
+
+int dcd_policy_cell_heads(const DcdStudentNet* net, const float* packed, const float* gates, const float* hc_in, const float* masks, float* hc_out,
+                          float* value, int64_t* action, float* action_log_prob, float* action_log_dist, float* u_out,
+                          uint32_t seed, uint32_t counter, const uint32_t* counter_base, int64_t env_index_base, int32_t deterministic, int32_t B, void* stream) {
+  DcdPolicyAgent a{};
+  a.net = net; a.packed = packed; a.gates = gates; a.hc_in = hc_in; a.masks = masks; a.hc_out = hc_out; a.value = value; a.action = action;
+  a.log_prob = action_log_prob; a.log_dist = action_log_dist; a.u_out = u_out; a.seed = seed; a.counter = counter; a.counter_base = counter_base;
+  a.env_index_base = env_index_base; a.deterministic = deterministic;
+  return cell_heads_sets(&a, nullptr, B, stream, "dcd_policy_cell_heads");
+}
+
+int dcd_policy_cell_heads_pair(const DcdPolicyAgent* a0, const DcdPolicyAgent* a1, int32_t B, void* stream) {
+  if (!a0 || !a1) return dcd::fail("dcd_policy_cell_heads_pair: NULL agent");
+  return cell_heads_sets(a0, a1, B, stream, "dcd_policy_cell_heads_pair");
 }
 
 int dcd_lstm_seq_fwd_step(float* gates, const float* c_prev, const float* m_t, const float* m_next, float* c_out, float* h_out,
@@ -679,8 +820,8 @@ int dcd_grid_delta_tiles(int32_t S, int32_t B) {
 
 int dcd_grid_delta_rows(const DcdStudentNet* net, const uint8_t* image_u8, const uint8_t* prev_u8, int64_t prev_env_stride,
                         int32_t* cell, int32_t* count, int32_t* src, float* rows, int32_t* tile_pos, int32_t n_tiles,
-                        int32_t* err, int32_t B, void* stream) {
-  if (!net || !image_u8 || !prev_u8 || !cell || !count || !src || !rows || !tile_pos || !err || B <= 0)
+                        int32_t* n_used, int32_t* err, int32_t B, void* stream) {
+  if (!net || !image_u8 || !prev_u8 || !cell || !count || !src || !rows || !tile_pos || !n_used || !err || B <= 0)
     return dcd::fail("dcd_grid_delta_rows: NULL pointer or empty batch");
   if (net->V < 3 || net->V > GMAXS || net->F < 1 || net->F > GMAXF || !net->conv_w || !net->conv_b)
     return dcd::fail("dcd_grid_delta_rows: grid size must be 3..17, F <= 128, conv weights set");
@@ -693,8 +834,29 @@ int dcd_grid_delta_rows(const DcdStudentNet* net, const uint8_t* image_u8, const
                      cell, src, err);
   hipLaunchKernelGGL(grid_bin_rank_kernel, dim3((unsigned)P), dim3(256), 0, st, (const int32_t*)cell, S, B, src, count);
   hipLaunchKernelGGL(grid_delta_rows_kernel, dim3((unsigned)((B + DE - 1) / DE)), dim3(256), 0, st, *net, image_u8, prev_u8,
-                     (long long)prev_env_stride, (const int32_t*)cell, (const int32_t*)count, src, rows, tile_pos, n_tiles, B, err);
+                     (long long)prev_env_stride, (const int32_t*)cell, (const int32_t*)count, src, rows, tile_pos, n_tiles, n_used, B, err);
   if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_grid_delta_rows: launch failed");
+  return 0;
+}
+int dcd_grid_tile_gemm(const float* rows, const float* wp, const int32_t* tile_pos, const int32_t* n_used, float* y, int32_t n_tiles,
+                       int32_t F, int32_t G, void* stream) {
+  if (!rows || !wp || !tile_pos || !n_used || !y || n_tiles <= 0) return dcd::fail("dcd_grid_tile_gemm: NULL pointer or no tiles");
+  if (F < 4 || F > GMAXF || (F & 3) || G < 128 || (G & 127)) return dcd::fail("dcd_grid_tile_gemm: F must be a multiple of 4 up to 128, G a multiple of 128");
+  if (((uintptr_t)rows | (uintptr_t)wp | (uintptr_t)y) & 15) return dcd::fail("dcd_grid_tile_gemm: rows / wp / y must be 16-byte aligned");
+  static_assert(DR == 128, "grid_tile_gemm_kernel computes 128-row tiles");
+  const size_t lds = (size_t)(DR * GA_P + F * 128) * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    const int cap = (int)(DR * GA_P + GMAXF * 128) * (int)sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grid_tile_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&grid_tile_gemm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess)
+      return dcd::fail("dcd_grid_tile_gemm: cannot reserve %zu bytes of LDS", lds);
+    once = true;
+  }
+  const dim3 grid((unsigned)n_tiles * (unsigned)(G / 128));
+  if (F == 128) hipLaunchKernelGGL(grid_tile_gemm_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, rows, wp, tile_pos, n_used, y, F, G);
+  else hipLaunchKernelGGL(grid_tile_gemm_kernel<0>, grid, dim3(256), lds, (hipStream_t)stream, rows, wp, tile_pos, n_used, y, F, G);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_grid_tile_gemm: launch failed");
   return 0;
 }
 

@@ -23,12 +23,22 @@ class StudentNet(C.Structure):
                [(k, C.c_int32) for k in ("V", "F", "E", "D", "H", "A1", "C1", "NA")]
 
 
+class PolicyAgent(C.Structure):
+    """DcdPolicyAgent (include/dcd_hip.h): one student's pointers for the two-students-per-launch entry points."""
+    _fields_ = [(k, C.c_void_p) for k in ("net", "packed", "image_u8", "dir_u8", "hc_in", "masks", "x", "gates", "hc_out", "value",
+                                          "action", "log_prob", "log_dist", "u_out", "counter_base")] + \
+               [("env_index_base", C.c_int64), ("seed", C.c_uint32), ("counter", C.c_uint32), ("deterministic", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 def enabled():
     return os.environ.get("DCD_FUSED_ACT", "1") != "0"
 
 
 class StudentActor:
-    def __init__(self, net, num_envs, seed=0, env_index_base=0):
+    def __init__(self, net, num_envs, seed=0, env_index_base=0, buffers=None):
+        """buffers: optional (x, gates, w_t, bias) tensors to use instead of own allocations — `PairedStudentActors` hands
+        each of two actors one half of [2, ...] tensors so that both GEMMs of a step are one batched GEMM."""
         self.net, self.B = net, int(num_envs)
         self.seed, self.env_index_base = int(seed) & 0xFFFFFFFF, int(env_index_base)
         self.counter = 0                                            # immediate part of the Philox counter (step index)
@@ -46,11 +56,19 @@ class StudentActor:
                           H=self.H, A1=a1.out_features, C1=c1.out_features, NA=a2.out_features)
         self._lstm = lstm
         self.K = self._dims["F"] * (V - 2) ** 2 + self._dims["E"] + self.H
-        self.KP = (self.K + 31) // 32 * 32                             # K padded for the GEMM (405 -> 416): zero columns / rows
-        self.x = torch.zeros((self.B, self.KP), device=dev)
-        self.gates = torch.empty((self.B, 4 * self.H), device=dev)
-        self.w_t = torch.zeros((self.KP, 4 * self.H), device=dev)     # persistent: captured HIP graphs keep pointing at them
-        self.bias = torch.empty((4 * self.H,), device=dev)
+        # K padded for the GEMM (405 -> 416) with at least one spare column: column K of x is the constant 1 and row K of the
+        # stacked weight is b_ih + b_hh, i.e. the bias is one more term of every dot product and the GEMM needs no bias
+        # operand (a batched GEMM with a broadcast bias costs an extra 33 MB copy per step); the other pad columns are zero
+        self.KP = (self.K + 1 + 31) // 32 * 32
+        if buffers is not None:
+            self.x, self.gates, self.w_t, self.bias = buffers
+            assert self.x.shape == (self.B, self.KP) and self.w_t.shape == (self.KP, 4 * self.H) and self.x.is_contiguous()
+        else:
+            self.x = torch.zeros((self.B, self.KP), device=dev)
+            self.gates = torch.empty((self.B, 4 * self.H), device=dev)
+            self.w_t = torch.zeros((self.KP, 4 * self.H), device=dev)     # persistent: captured HIP graphs keep pointing at them
+            self.bias = torch.empty((4 * self.H,), device=dev)
+        self.x[:, self.K] = 1.0
         self.packed = torch.empty((lib().dcd_policy_packed_heads_floats(),), device=dev)   # head weights in the kernel's layout
         self.counter_base = torch.zeros(1, dtype=torch.int32, device=dev)   # device part of the counter (rollouts so far x T)
         self._struct = None
@@ -79,10 +97,41 @@ class StudentActor:
         return a1.out_features + c1.out_features <= 64 and a2.out_features < 16 and net.critic[1].out_features == 1
 
     @classmethod
-    def try_create(cls, net, num_envs, seed=0, env_index_base=0):
+    def try_create(cls, net, num_envs, seed=0, env_index_base=0, buffers=None):
         if not enabled() or not cls.supported(net):
             return None
-        return cls(net, num_envs, seed=seed, env_index_base=env_index_base)
+        return cls(net, num_envs, seed=seed, env_index_base=env_index_base, buffers=buffers)
+
+    @staticmethod
+    def input_pitch(net):
+        """KP of a supported network (the GEMM operand's row pitch): known before the actor exists."""
+        conv = net.image_conv[0]
+        k = net.image_embedding_size + net.scalar_embed.out_features + net.rnn.rnn.hidden_size
+        return (k + 1 + 31) // 32 * 32
+
+    def agent_struct(self, st, step, deterministic=False):
+        """DcdPolicyAgent for `act_storage(st, step)` (u8 rollout buffers)."""
+        B, H, V, NA = self.B, self.H, self._dims["V"], self._dims["NA"]
+        o = st.obs_u8
+        a = PolicyAgent()
+        self._struct_keep = self._struct
+        a.net = C.addressof(self._struct)
+        a.packed = ptr(self.packed).value
+        a.image_u8 = ptr(o["image"][step], torch.uint8, B * 3 * V * V, "image_u8").value
+        a.dir_u8 = ptr(o["direction"][step], torch.uint8, B, "dir_u8").value
+        a.hc_in = ptr(st.recurrent_hidden_states[step], torch.float32, B * 2 * H, "hc_in").value
+        a.masks = ptr(st.masks[step], torch.float32, B, "masks").value
+        a.x, a.gates = ptr(self.x).value, ptr(self.gates).value
+        a.hc_out = ptr(st.recurrent_hidden_states[step + 1], torch.float32, B * 2 * H, "hc_out").value
+        a.value = ptr(st.value_preds[step], torch.float32, B, "value").value
+        a.action = ptr(st.actions[step], torch.int64, B, "action").value
+        a.log_prob = ptr(st.action_log_probs[step], torch.float32, B, "log_prob").value
+        a.log_dist = ptr(st.action_log_dist[step], torch.float32, B * NA, "log_dist").value
+        a.u_out = None
+        a.counter_base = self.counter_base.data_ptr()
+        a.env_index_base = self.env_index_base
+        a.seed, a.counter, a.deterministic = self.seed, step & 0xFFFFFFFF, int(deterministic)
+        return a
 
     def refresh(self):
         """Re-read parameter pointers and rebuild, IN PLACE, the two derived buffers — the stacked LSTM weight
@@ -97,6 +146,7 @@ class StudentActor:
             self.w_t[:self.K - self.H].copy_(l.weight_ih_l0.t())       # [K, 4H] = [W_ih | W_hh]^T, refreshed in place
             self.w_t[self.K - self.H:self.K].copy_(l.weight_hh_l0.t())
             torch.add(l.bias_ih_l0, l.bias_hh_l0, out=self.bias)
+            self.w_t[self.K].copy_(self.bias)
         s = StudentNet()
         for name, p in zip([f[0] for f in StudentNet._fields_[:12]], self._params):
             setattr(s, name, ptr(p.detach(), torch.float32, name=name).value)
@@ -124,7 +174,7 @@ class StudentActor:
             check(L.dcd_policy_features(C.byref(s), ptr(image, torch.float32, B * 3 * self._dims["V"] ** 2, "image"),
                                         ptr(direction, torch.float32, B, "direction"), ptr(hc_in, torch.float32, B * 2 * self.H, "hc_in"),
                                         ptr(masks, torch.float32, B, "masks"), ptr(self.x), C.c_int32(self.KP), C.c_int32(B), stream_ptr()))
-        torch.addmm(self.bias, self.x, self.w_t, out=self.gates)
+        torch.mm(self.x, self.w_t, out=self.gates)
         check(L.dcd_policy_cell_heads(C.byref(s), ptr(self.packed), ptr(self.gates), ptr(hc_in), ptr(masks), ptr(hc_out, torch.float32, B * 2 * self.H, "hc_out"),
                                       ptr(value, torch.float32, B, "value"), ptr(action, torch.int64, B, "action"),
                                       ptr(log_prob, torch.float32, B, "log_prob"),
@@ -166,6 +216,41 @@ class StudentActor:
         self.act_into(o["image"][step], o["direction"][step], st.recurrent_hidden_states[step], st.masks[step],
                       hc, st.value_preds[step], action, log_prob, log_dist, deterministic=True)
         return st.value_preds[step]
+
+
+class PairedStudentActors:
+    """Two StudentActors of one geometry (PAIRED's protagonist and antagonist) acting at the same step of their lock-step
+    rollouts: ONE features launch, ONE batched GEMM, ONE cell + heads launch for both (dcd_policy_features_u8_pair,
+    dcd_policy_cell_heads_pair).  The actors must have been created on the halves of `buffers(...)`."""
+
+    @staticmethod
+    def buffers(nets, num_envs):
+        """[2, ...] operand / gate / weight / bias tensors for two supported networks, or None if their shapes differ."""
+        kp = [StudentActor.input_pitch(n) for n in nets]
+        hs = [n.rnn.rnn.hidden_size for n in nets]
+        if len(nets) != 2 or kp[0] != kp[1] or hs[0] != hs[1]:
+            return None
+        dev, B, G = nets[0].image_conv[0].weight.device, int(num_envs), 4 * hs[0]
+        return dict(x=torch.zeros((2, B, kp[0]), device=dev), gates=torch.empty((2, B, G), device=dev),
+                    w_t=torch.zeros((2, kp[0], G), device=dev), bias=torch.empty((2, 1, G), device=dev))
+
+    @staticmethod
+    def half(buf, k):
+        return buf["x"][k], buf["gates"][k], buf["w_t"][k], buf["bias"][k, 0]
+
+    def __init__(self, actors, buf):
+        self.actors, self.buf = tuple(actors), buf
+        for k, a in enumerate(self.actors):
+            assert a.x.data_ptr() == buf["x"][k].data_ptr() and a.w_t.data_ptr() == buf["w_t"][k].data_ptr()
+
+    def act_storage(self, sts, step, deterministic=False):
+        L, B = lib(), self.actors[0].B
+        a0, a1 = (f.agent_struct(st, step, deterministic) for f, st in zip(self.actors, sts))
+        check(L.dcd_policy_features_u8_pair(C.byref(a0), C.byref(a1), C.c_int32(self.actors[0].KP), C.c_int32(B), stream_ptr()))
+        torch.bmm(self.buf["x"], self.buf["w_t"], out=self.buf["gates"])
+        check(L.dcd_policy_cell_heads_pair(C.byref(a0), C.byref(a1), C.c_int32(B), stream_ptr()))
+        for f in self.actors:
+            f.counter = step + 1
 
 
 _DIV10 = {}
@@ -337,15 +422,15 @@ class GridActor:
             i32 = dict(dtype=torch.int32, device=dev)
             self._d = dict(Tt=Tt, R=R, cell=torch.zeros(B, **i32), count=torch.zeros(P, **i32), src=torch.full((B, 9), -1, **i32),
                            rows=torch.zeros((Tt * R, F), device=dev), tile=torch.zeros(Tt, **i32),
-                           wg=torch.empty((Tt, F, G), device=dev), y=torch.empty((Tt * R, G), device=dev),
+                           y=torch.zeros((Tt * R, G), device=dev), used=torch.zeros(1, **i32),
                            err=torch.zeros(1, **i32), xp=torch.empty((B, G), device=dev))
         return self._d
 
     def _carry_projection_device(self, image, prev_image):
         """`_carry_projection` for raw u8 images with nothing read back: `dcd_grid_delta_rows` finds each env's changed
         cell, bins the (env, conv position) pairs by position in env order and writes their feature differences as
-        fixed-height tiles; ONE batched GEMM over a fixed number of tiles multiplies each tile by its position's weight block
-        (gathered by the device-side tile table); dcd_gather_sum_rows adds an env's <= 9 rows in slot order.  The first
+        128-row tiles; `dcd_grid_tile_gemm` (fp32 MFMA) multiplies each tile that holds rows by its position's weight
+        block, found through the device-side tile table; dcd_gather_sum_rows adds an env's <= 9 rows in slot order.  The first
         step takes env 0's image as every env's previous image (after the teacher's reset all grids are the same empty
         room; a grid that differs from it in one cell is still exact).  More than one changed cell in a step sets an error
         word that `check_carry_errors` turns into an exception."""
@@ -364,9 +449,16 @@ class GridActor:
                                     ptr(prev_image, torch.uint8, S * S * 3 * (B if stride else 1), "prev_u8"), C.c_int64(stride),
                                     ptr(d["cell"], torch.int32), ptr(d["count"], torch.int32), ptr(d["src"], torch.int32),
                                     ptr(d["rows"], torch.float32), ptr(d["tile"], torch.int32), C.c_int32(d["Tt"]),
-                                    ptr(d["err"], torch.int32), C.c_int32(B), stream_ptr()))
-        torch.index_select(self.wp, 0, d["tile"], out=d["wg"])
-        torch.bmm(d["rows"].view(d["Tt"], d["R"], F), d["wg"], out=d["y"].view(d["Tt"], d["R"], G))
+                                    ptr(d["used"], torch.int32), ptr(d["err"], torch.int32), C.c_int32(B), stream_ptr()))
+        if os.environ.get("DCD_TILE_GEMM", "1") != "0":                # fp32 MFMA over the tiles that hold rows, weight blocks read in place
+            check(L.dcd_grid_tile_gemm(ptr(d["rows"], torch.float32), ptr(self.wp, torch.float32), ptr(d["tile"], torch.int32),
+                                       ptr(d["used"], torch.int32), ptr(d["y"], torch.float32), C.c_int32(d["Tt"]), C.c_int32(F),
+                                       C.c_int32(G), stream_ptr()))
+        else:                                                          # rocBLAS batched GEMM over ALL tiles on gathered weight blocks
+            if "wg" not in d:
+                d["wg"] = torch.empty((d["Tt"], F, G), device=self.wp.device)
+            torch.index_select(self.wp, 0, d["tile"], out=d["wg"])
+            torch.bmm(d["rows"].view(d["Tt"], d["R"], F), d["wg"], out=d["y"].view(d["Tt"], d["R"], G))
         check(L.dcd_gather_sum_rows(ptr(d["y"], torch.float32), ptr(d["src"], torch.int32), ptr(d["xp"], torch.float32), C.c_int32(B),
                                     C.c_int32(9), C.c_int32(G), stream_ptr()))
         return True

@@ -126,6 +126,7 @@ class AdversarialRunner:
         # DCD_PAIR_ROLLOUT=1 (default): in a PAIRED update without level replay the protagonist's and the antagonist's
         # rollouts advance in lock-step, ONE env-step launch for both (dcd_mg_step_pair) on two copies of the levels.
         self.pair_rollouts = os.environ.get("DCD_PAIR_ROLLOUT", "1") != "0" and self.device.type == "cuda"
+        self.pair_policy_launches = self.pair_rollouts and os.environ.get("DCD_PAIR_POLICY", "1") != "0"
         # DCD_U8_OBS=1 (default): the students' rollout buffers hold the RAW observation bytes (76 B per env-step instead of
         # 304 B of preprocessed fp32); the fused policy step reads them, fp32 views are derived for the PPO batch
         if os.environ.get("DCD_U8_OBS", "1") != "0" and self.device.type == "cuda":
@@ -531,14 +532,33 @@ class AdversarialRunner:
         GEMM), or None when the network is not student-shaped / DCD_FUSED_ACT=0: then the PyTorch modules run."""
         fa = getattr(agent, "_fused_actor", False)
         if fa is False:
-            from dcd_hip.policy import StudentActor
-            k = [a for a in self.agents.values() if a is not None].index(agent) if agent in self.agents.values() else 0
-            fa = None
-            if self.device.type == "cuda":
-                fa = StudentActor.try_create(agent.actor_critic, self.args.num_processes,
-                                             seed=(self.args.seed * 2654435761 + 97 * k + 1) & 0xFFFFFFFF,
-                                             env_index_base=getattr(self.venv, "env_index_base", 0))
-            agent._fused_actor = fa
+            from dcd_hip.policy import PairedStudentActors, StudentActor, enabled
+            live = [a for a in self.agents.values() if a is not None]
+            students = [self.agents.get("agent"), self.agents.get("adversary_agent")]
+            group, buf = [agent], None
+            # PAIRED: both students' actors are created together on the halves of shared [2, ...] operand / weight tensors, so
+            # that a lock-step rollout runs ONE features launch, ONE batched GEMM and ONE cell + heads launch per step for
+            # both (the buffers are fixed before any graph is captured)
+            if (self.device.type == "cuda" and enabled() and self.pair_policy_launches and all(a is not None for a in students)
+                    and any(a is agent for a in students)
+                    and all(StudentActor.supported(a.actor_critic) and getattr(a, "_fused_actor", False) is False for a in students)):
+                buf = PairedStudentActors.buffers([a.actor_critic for a in students], self.args.num_processes)
+                if buf is not None:
+                    group = students
+            made = []
+            for j, ag in enumerate(group):
+                k = live.index(ag) if ag in live else 0
+                f = None
+                if self.device.type == "cuda":
+                    f = StudentActor.try_create(ag.actor_critic, self.args.num_processes,
+                                                seed=(self.args.seed * 2654435761 + 97 * k + 1) & 0xFFFFFFFF,
+                                                env_index_base=getattr(self.venv, "env_index_base", 0),
+                                                buffers=PairedStudentActors.half(buf, j) if buf is not None and len(group) == 2 else None)
+                ag._fused_actor = f
+                made.append(f)
+            if len(group) == 2 and all(f is not None for f in made):
+                self._pair_actors = PairedStudentActors(made, buf)
+            fa = agent._fused_actor
         if fa is not None and agent.actor_critic.random:
             return None
         return fa
@@ -627,10 +647,18 @@ class AdversarialRunner:
             venv.reset_agent_device(sts[0].student_obs_out(0))
             venv.reset_agent_twin_device(sts[1].student_obs_out(0))
         fused = [self._fused_actor(a) if self.is_discrete_actions else None for a in agents]
+        pa = getattr(self, "_pair_actors", None)
+        both = (pa is not None and all(f is not None for f in fused) and all(f is g for f, g in zip(fused, pa.actors))
+                and all(st.obs_u8 is not None for st in sts))
         for st in sts:
             st.step = t0
         for step in range(t0, t1):
-            for agent, st, f in zip(agents, sts, fused):
+            if both:                                                    # one launch of each policy kernel for both students
+                pa.act_storage(sts, step)
+                if track_seeds:
+                    for st in sts:
+                        st.level_seeds[step].copy_(self._seeds_dev)
+            for agent, st, f in zip(agents, sts, fused) if not both else ():
                 if f is not None:
                     f.act_storage(st, step)
                     if track_seeds:

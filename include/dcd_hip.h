@@ -423,6 +423,32 @@ int dcd_policy_cell_heads(const DcdStudentNet* net, const float* packed, const f
                           float* action_log_dist, float* u_out, uint32_t seed, uint32_t counter,
                           const uint32_t* counter_base, int64_t env_index_base, int32_t deterministic, int32_t B, void* stream);
 
+/* Two students per launch (PAIRED: the protagonist's and the antagonist's `act` at the same step of their lock-step rollouts,
+ * adversarial_runner.py:709-733 + 506-517): every pointer of dcd_policy_features_u8 / dcd_policy_cell_heads once per agent.
+ * The two networks must have one geometry.  The caller forms both gates tensors between the two calls (one batched GEMM). */
+typedef struct DcdPolicyAgent {
+  const DcdStudentNet* net;
+  const float* packed;                  /* dcd_policy_pack_heads of `net` */
+  const uint8_t* image_u8;              /* features: observation bytes, state in, operand row out */
+  const uint8_t* dir_u8;
+  const float* hc_in;
+  const float* masks;
+  float* x;
+  const float* gates;                   /* cell + heads */
+  float* hc_out;
+  float* value;
+  int64_t* action;
+  float* log_prob;
+  float* log_dist;
+  float* u_out;                         /* optional */
+  const uint32_t* counter_base;         /* optional device word */
+  int64_t env_index_base;
+  uint32_t seed, counter;
+  int32_t deterministic, reserved;
+} DcdPolicyAgent;
+int dcd_policy_features_u8_pair(const DcdPolicyAgent* a0, const DcdPolicyAgent* a1, int32_t x_pitch, int32_t B, void* stream);
+int dcd_policy_cell_heads_pair(const DcdPolicyAgent* a0, const DcdPolicyAgent* a1, int32_t B, void* stream);
+
 /* ---- masked LSTM sequence of the PPO update (models/common.py:157-207) ------------------ */
 /* The reference cuts the flattened (T*N) sequence wherever ANY env has mask 0 and re-masks the state at each
  * cut — the same function as multiplying (h, c) by masks[t] before every step.  One step of that recurrence
@@ -457,15 +483,22 @@ int dcd_gather_sum_rows(const float* y, const int32_t* src, float* out, int32_t 
  *                       tiles, rows inside a bin in env order (so no result depends on scheduling);
  *   rows  float[n_tiles*R, F]   relu(conv)(new window) - relu(conv)(old window) of every pair (other rows: not written);
  *   tile_pos int32[n_tiles]     the position whose weight block multiplies tile t (tiles past the last bin: any valid index);
+ *   n_used int32[1]     number of tiles that hold rows (the bins' padded sizes / R);
  *   err   int32[1]      |= 1 if some env changed in more than one cell, |= 2 on tile overflow (cannot happen with
  *                       n_tiles >= dcd_grid_delta_tiles(S, B) = ceil((9 B + (R-1) (S-2)^2) / R), R = dcd_grid_delta_tile_rows()).
- * The caller then runs Y[t] = rows[t] @ Wp[tile_pos[t]] for all tiles and dcd_gather_sum_rows(Y, src, xp, B, 9, 4H).
+ * The caller then runs Y[t] = rows[t] @ Wp[tile_pos[t]] (dcd_grid_tile_gemm) and dcd_gather_sum_rows(Y, src, xp, B, 9, 4H).
  * Only V (= S), F, conv_w, conv_b of `net` are read. */
 int dcd_grid_delta_tile_rows(void);
 int dcd_grid_delta_tiles(int32_t S, int32_t B);
 int dcd_grid_delta_rows(const DcdStudentNet* net, const uint8_t* image_u8, const uint8_t* prev_u8, int64_t prev_env_stride,
                         int32_t* cell, int32_t* count, int32_t* src, float* rows, int32_t* tile_pos, int32_t n_tiles,
-                        int32_t* err, int32_t B, void* stream);
+                        int32_t* n_used, int32_t* err, int32_t B, void* stream);
+/* Y[t] = rows[t] @ wp[tile_pos[t]] for t < *n_used (device word): rows float[n_tiles*R, F] (R = dcd_grid_delta_tile_rows() =
+ * 128), wp float[(S-2)^2, F, G] the per-position blocks of the LSTM input weight (W_ih[:, f*P + p]^T), y float[n_tiles*R, G];
+ * F a multiple of 4 up to 128, G a multiple of 128, all three 16-byte aligned.  fp32 MFMA (v_mfma_f32_32x32x2_f32): every
+ * element is the k-ordered fmaf chain over the F features.  Tiles t >= *n_used are not computed (their y rows keep old values). */
+int dcd_grid_tile_gemm(const float* rows, const float* wp, const int32_t* tile_pos, const int32_t* n_used, float* y,
+                       int32_t n_tiles, int32_t F, int32_t G, void* stream);
 
 /* ---- logging statistics (HOST pointers — the only entry point that is not a device call) ------------------ */
 /* RolloutStorage.get_action_complexity / get_batched_action_complexity (algos/storage.py:329-369): LZ76 phrase

@@ -464,3 +464,78 @@ def test_grid_actor_device_carried_projection_matches_dense_operand(B):
     g1.check_carry_errors()
     assert (v0 - v1).abs().max().item() <= 2e-5 * max(v0.abs().max().item(), 1.0)
     venv.close()
+
+
+@pytest.mark.parametrize("F,G,n_tiles,n_used", [(128, 1024, 9, 7), (64, 256, 3, 3), (128, 1024, 2, 0)])
+def test_grid_tile_gemm_matches_fp32_fma_chain(F, G, n_tiles, n_used):
+    """dcd_grid_tile_gemm (v_mfma_f32_32x32x2_f32): y[t] = rows[t] @ wp[tile_pos[t]] for t < n_used — against the same
+    product in fp64 (|err| <= 2e-6 x sum |a b|: one fp32 rounding per product and per addition over K <= 128) and, exactly,
+    against the k-ordered fp32 fmaf chain the instruction is specified to compute (checked on a sample of elements);
+    tiles >= n_used keep their old contents."""
+    import ctypes as C
+    from dcd_hip import check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(F + n_tiles)
+    P, R = 5, lib().dcd_grid_delta_tile_rows()
+    rows = (torch.rand(n_tiles * R, F, generator=g) * 2 - 1).to(DEV)
+    wp = (torch.rand(P, F, G, generator=g) * 2 - 1).to(DEV)
+    tile = torch.randint(0, P, (n_tiles,), generator=g).to(torch.int32).to(DEV)
+    used = torch.tensor([n_used], dtype=torch.int32, device=DEV)
+    y = torch.full((n_tiles * R, G), 7.0, device=DEV)
+    check(lib().dcd_grid_tile_gemm(ptr(rows), ptr(wp), ptr(tile, torch.int32), ptr(used, torch.int32), ptr(y), C.c_int32(n_tiles),
+                                   C.c_int32(F), C.c_int32(G), stream_ptr()))
+    torch.cuda.synchronize()
+    a = rows.view(n_tiles, R, F).double()
+    w = wp[tile.long()].double()
+    want = torch.bmm(a, w)
+    bound = torch.bmm(a.abs(), w.abs()) * 2e-6 + 1e-30
+    got = y.view(n_tiles, R, G)
+    assert ((got[:n_used].double() - want[:n_used]).abs() <= bound[:n_used]).all()
+    assert (got[n_used:] == 7.0).all()
+    if n_used:
+        rows_h, wp_h, tile_h, got_h = rows.cpu().numpy(), wp.cpu().numpy(), tile.cpu().numpy(), got.cpu().numpy()
+        rng = np.random.default_rng(1)
+        for _ in range(64):
+            t, r, c = int(rng.integers(n_used)), int(rng.integers(R)), int(rng.integers(G))
+            acc = np.float32(0)
+            for k in range(F):                                       # fmaf(a_k, b_k, acc): the product is exact in fp64, one rounding
+                acc = np.float32(np.float64(rows_h[t * R + r, k]) * np.float64(wp_h[tile_h[t], k, c]) + np.float64(acc))
+            assert got_h[t, r, c] == acc, (t, r, c)
+
+
+def test_paired_student_actors_equal_two_single_actors():
+    """dcd_policy_features_u8_pair + one batched GEMM + dcd_policy_cell_heads_pair (both PAIRED students per launch) write
+    exactly what two single-agent act_storage calls write: every policy field of both storages, bit for bit."""
+    from algos import RolloutStorage
+    from envs import spaces
+    from dcd_hip.policy import PairedStudentActors, StudentActor
+    B, T = 200, 3
+    nets = [_net(11), _net(12)]
+    obs = {"image": spaces.Box(0, 255, (3, 5, 5), "uint8"), "direction": spaces.Box(0, 3, (1,), "uint8")}
+    def storages():
+        out = []
+        for k, net in enumerate(nets):
+            st = RolloutStorage(net, T, B, obs, spaces.Discrete(7), 256, recurrent_arch="lstm", use_proper_time_limits=True, device=DEV)
+            st.enable_u8_obs()
+            g = torch.Generator().manual_seed(100 + k)
+            st.obs_u8["image"].copy_(torch.randint(0, 11, st.obs_u8["image"].shape, generator=g).to(torch.uint8))
+            st.obs_u8["direction"].copy_(torch.randint(0, 4, st.obs_u8["direction"].shape, generator=g).to(torch.uint8))
+            st.recurrent_hidden_states[0].copy_(torch.rand(B, 512, generator=g) * 2 - 1)
+            st.masks.copy_((torch.rand(T + 1, B, 1, generator=g) > 0.2).float())
+            out.append(st)
+        return out
+    buf = PairedStudentActors.buffers(nets, B)
+    paired = [StudentActor(n, B, seed=5 + k, env_index_base=64, buffers=PairedStudentActors.half(buf, k)) for k, n in enumerate(nets)]
+    single = [StudentActor(n, B, seed=5 + k, env_index_base=64) for k, n in enumerate(nets)]
+    pa = PairedStudentActors(paired, buf)
+    sp, ss = storages(), storages()
+    for f in paired + single:
+        f.begin_rollout(T)
+    for step in range(T):
+        pa.act_storage(sp, step)
+        for f, st in zip(single, ss):
+            f.act_storage(st, step)
+    torch.cuda.synchronize()
+    for a, b in zip(sp, ss):
+        for k in ("value_preds", "actions", "action_log_probs", "action_log_dist", "recurrent_hidden_states"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), k
+    assert not torch.equal(sp[0].actions, sp[1].actions)             # two different policies / streams
