@@ -551,6 +551,166 @@ __global__ void __launch_bounds__(256) grid_delta_rows_kernel(DcdStudentNet n, c
   }
 }
 
+// ---- the teacher's rollout step around its two GEMMs: operand row of everything but the image, then cell + heads ------
+// x_rest[b] = [scalar_embed(one_hot(scalar[b])) | z[b] | h[b]*mask[b] | 1 | 0...]  (multigrid_models.py:119-131 minus the
+// conv features, whose projection is carried: dcd_grid_delta_rows).  The 1 multiplies the bias row of the stacked weight.
+__global__ void __launch_bounds__(256) grid_rest_features_kernel(DcdStudentNet n, const float* __restrict__ scalar, const float* __restrict__ z,
+                                                                 int Z, const float* __restrict__ hc, const float* __restrict__ masks,
+                                                                 float* __restrict__ x, int KP, int B) {
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int b = (int)(q / KP), k = (int)(q - (long long)b * KP);
+  if (b >= B) return;
+  const int E = n.E, H = n.H;
+  float v = 0.f;
+  if (k < E) { int d = (int)scalar[b]; d = d < 0 ? 0 : (d >= n.D ? n.D - 1 : d); v = n.embed_w[k * n.D + d] + n.embed_b[k]; }
+  else if (k < E + Z) v = z[(size_t)b * Z + (k - E)];
+  else if (k < E + Z + H) v = hc[(size_t)b * 2 * H + (k - E - Z)] * masks[b];
+  else if (k == E + Z + H) v = 1.f;
+  x[(size_t)b * KP + k] = v;
+}
+
+// Wide heads (the teacher: 169 actions).  Packed layout: w1t [H][64] stacked [actor | critic] first layers transposed, b1 [64],
+// w2 [NA + 1][WW2P] (row a < NA: actor output a over the A1 actor units; row NA: the critic output over the C1 critic units,
+// both starting at column 0; pitch 33: the 64 lanes of a wave read 64 different rows conflict-free), b2 [NA + 1].
+constexpr int WW2P = 33, WMAXA = 192;
+__host__ __device__ constexpr int wide_w2(int) { return MAXH * 64 + 64; }
+__host__ __device__ inline int wide_b2(int NA) { return MAXH * 64 + 64 + (NA + 1) * WW2P; }
+__host__ __device__ inline int wide_floats(int NA) { return (wide_b2(NA) + NA + 1 + 3) / 4 * 4; }
+
+__global__ void __launch_bounds__(PB) wide_heads_pack_kernel(DcdStudentNet n, float* __restrict__ pk) {
+  const int q = blockIdx.x * PB + threadIdx.x, H = n.H, U = n.A1 + n.C1, NA = n.NA;
+  if (q >= wide_floats(NA)) return;
+  float w = 0.f;
+  if (q < MAXH * 64) { const int k = q >> 6, u = q & 63; w = u < n.A1 ? n.actor_w1[u * H + k] : (u < U ? n.critic_w1[(u - n.A1) * H + k] : 0.f); }
+  else if (q < wide_w2(0)) { const int u = q - MAXH * 64; w = u < n.A1 ? n.actor_b1[u] : (u < U ? n.critic_b1[u - n.A1] : 0.f); }
+  else if (q < wide_b2(NA)) {
+    const int r = (q - wide_w2(0)) / WW2P, u = (q - wide_w2(0)) % WW2P;
+    if (r < NA && u < n.A1) w = n.actor_w2[r * n.A1 + u];
+    else if (r == NA && u < n.C1) w = n.critic_w2[u];
+  } else { const int r = q - wide_b2(NA); if (r < NA) w = n.actor_b2[r]; else if (r == NA) w = n.critic_b2[0]; }
+  pk[q] = w;
+}
+
+// Same cell and first head layer as policy_cell_heads_kernel (8 waves x 2 envs); the second layer, the log-softmax and the
+// draw take a whole wave per env: lane l owns outputs l, l + 64, l + 128 (< NA; output NA is the value).  Inverse CDF in
+// index order: per 64-group an inclusive wave scan of the probabilities, group offsets added, first output whose cumulative
+// probability exceeds the uniform (ballot per group).  One Philox uniform per (env, counter), as for the students.
+template <int H>
+__global__ void __launch_bounds__(CB) wide_cell_heads_kernel(DcdStudentNet n, const float* __restrict__ packed, CellArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int NA = n.NA, PKF = wide_floats(NA);
+  float* s_pk = smem;
+  float* s_h = s_pk + PKF;                          // [CW waves][H][EW envs]
+  float* s_t = s_h + CW * H * EW;                   // [CW waves][EW envs][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int q = tid; q < PKF / 4; q += CB) reinterpret_cast<float4*>(s_pk)[q] = reinterpret_cast<const float4*>(packed)[q];
+  const uint32_t ctr = a.counter + (a.counter_base ? *a.counter_base : 0u);
+  float* hb = s_h + wave * H * EW;
+  float* tb = s_t + wave * EW * 64;
+  const int b0 = blockIdx.x * HE + wave * EW;
+#pragma unroll
+  for (int e = 0; e < EW; ++e) {                                       // nn.LSTM cell, gate order i,f,g,o
+    const int b = b0 + e;
+    if (b < a.B) {
+      const float m = a.masks[b];
+      const float* g = a.gates + (size_t)b * 4 * H;
+      const float* ci = a.hc_in + (size_t)b * 2 * H + H;
+      float* ho = a.hc_out + (size_t)b * 2 * H;
+#pragma unroll
+      for (int q = 0; q < H / 64; ++q) {
+        const int j = lane + 64 * q;
+        const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+        const float c = fast_sigmoid(gf) * (ci[j] * m) + fast_sigmoid(gi) * fast_tanh(gg);
+        const float h = fast_sigmoid(go) * fast_tanh(c);
+        ho[j] = h; ho[H + j] = c; hb[j * EW + e] = h;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < H / 64; ++q) hb[(lane + 64 * q) * EW + e] = 0.f;
+    }
+  }
+  __syncthreads();
+  {                                                                   // Linear(H -> A1 | C1) + Tanh
+    const float* w1 = s_pk;
+    const float bias = s_pk[MAXH * 64 + lane];
+    static_assert(EW == 2, "the layer-1 loop reads the wave's h values as one float2");
+    float a0 = bias, a1 = bias;
+#pragma unroll 8
+    for (int k = 0; k < H; ++k) {
+      const float w = w1[k * 64 + lane];
+      const float2 h2 = *reinterpret_cast<const float2*>(hb + k * 2);
+      a0 = fmaf(w, h2.x, a0); a1 = fmaf(w, h2.y, a1);
+    }
+    tb[lane] = fast_tanh(a0); tb[64 + lane] = fast_tanh(a1);
+  }
+  __syncthreads();
+  const float* w2 = s_pk + wide_w2(0);
+  const float* b2 = s_pk + wide_b2(NA);
+  for (int e = 0; e < EW; ++e) {
+    const int b = b0 + e;
+    if (b >= a.B) break;                                               // wave-uniform
+    const float* t = tb + e * 64;
+    float lg[3], out[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int o = lane + 64 * r;
+      float acc = 0.f;
+      if (o <= NA) {
+        acc = b2[o];
+        const float* wr = w2 + o * WW2P;
+        const float* tt = o < NA ? t : t + n.A1;
+        const int nu = o < NA ? n.A1 : n.C1;
+        for (int u = 0; u < nu; ++u) acc = fmaf(wr[u], tt[u], acc);
+      }
+      out[r] = acc;
+      lg[r] = o < NA ? acc : -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(lg[0], lg[1]), lg[2]);
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+    float ex[3], sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { ex[r] = (lane + 64 * r) < NA ? expf(lg[r] - mx) : 0.f; sum += ex[r]; }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) sum += __shfl_xor(sum, s);
+    const float lse = logf(sum);
+    float lsm[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      lsm[r] = lg[r] - mx - lse;
+      if (lane + 64 * r < NA) a.log_dist[(size_t)b * NA + lane + 64 * r] = lsm[r];
+    }
+    uint32_t r4[4];
+    dcd::philox4x32_10(ctr, (uint32_t)(a.env_index_base + b), (uint32_t)((a.env_index_base + b) >> 32), 0x504F4C31u,
+                       a.seed, 0x41435421u, r4);
+    const float u01 = (float)(r4[0] >> 8) * (1.0f / 16777216.0f);
+    int chosen = -1, arg = -1;
+    float base = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                                      // cumulative probabilities in index order
+      float cum = ex[r] / sum;
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) { const float v = __shfl_up(cum, s); if (lane >= s) cum += v; }
+      cum += base;
+      const unsigned long long hit = __ballot((lane + 64 * r) < NA && u01 < cum);
+      if (chosen < 0 && hit) chosen = 64 * r + __ffsll((long long)hit) - 1;
+      base = __shfl(cum, 63);
+      const unsigned long long top = __ballot((lane + 64 * r) < NA && lg[r] == mx);
+      if (arg < 0 && top) arg = 64 * r + __ffsll((long long)top) - 1;
+    }
+    if (chosen < 0) chosen = NA - 1;                                   // cumulative sum rounded below u
+    const int act = a.deterministic ? arg : chosen;
+    const int ar = act >> 6, al = act & 63;
+    const float lp = __shfl(ar == 0 ? lsm[0] : (ar == 1 ? lsm[1] : lsm[2]), al);
+    const int vr = NA >> 6, vl = NA & 63;
+    const float val = __shfl(vr == 0 ? out[0] : (vr == 1 ? out[1] : out[2]), vl);
+    if (lane == 0) {
+      a.value[b] = val; a.action[b] = act; a.logp[b] = lp;
+      if (a.u_out) a.u_out[b] = u01;
+    }
+  }
+}
+
 // ---- Y[t] = rows[t] @ Wp[tile_pos[t]]: the tiled product of the carried projection, fp32 MFMA ------------------------
 // One workgroup = one 128 x 128 block of Y: tile t (DR = 128 binned rows, K = F <= 128 features) x column block nb of the
 // position's weight block Wp[p] [F, G].  The whole K extent sits in LDS at once — A 128 x F (pitch 132: float4 stores,
@@ -838,6 +998,60 @@ int dcd_grid_delta_rows(const DcdStudentNet* net, const uint8_t* image_u8, const
   if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_grid_delta_rows: launch failed");
   return 0;
 }
+static int check_wide_net(const DcdStudentNet* n, const char* who) {
+  if (!n) return dcd::fail("%s: net is NULL", who);
+  if (n->H != MAXH) return dcd::fail("%s: hidden size %d unsupported (256)", who, n->H);
+  if (n->A1 < 1 || n->C1 < 1 || n->A1 + n->C1 > 64 || n->A1 >= WW2P || n->C1 >= WW2P) return dcd::fail("%s: head widths %d+%d unsupported (<= 32 each)", who, n->A1, n->C1);
+  if (n->NA < 1 || n->NA >= WMAXA) return dcd::fail("%s: %d actions unsupported (< 192)", who, n->NA);
+  if (!n->actor_w1 || !n->actor_b1 || !n->actor_w2 || !n->actor_b2 || !n->critic_w1 || !n->critic_b1 || !n->critic_w2 || !n->critic_b2)
+    return dcd::fail("%s: head weights not set", who);
+  return 0;
+}
+
+int dcd_policy_grid_rest_features(const DcdStudentNet* net, const float* scalar, const float* z, int32_t z_dim, const float* hc,
+                                  const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream) {
+  if (!net || !scalar || !hc || !masks || !x || (z_dim && !z) || B <= 0) return dcd::fail("dcd_policy_grid_rest_features: NULL pointer or B <= 0");
+  if (net->E < 0 || net->D < 1 || z_dim < 0 || net->H < 1 || x_pitch < net->E + z_dim + net->H + 1 || !net->embed_w || !net->embed_b)
+    return dcd::fail("dcd_policy_grid_rest_features: x_pitch %d < E + z_dim + H + 1, or embedding weights not set", x_pitch);
+  const long long total = (long long)B * x_pitch;
+  hipLaunchKernelGGL(grid_rest_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *net, scalar, z, z_dim, hc,
+                     masks, x, x_pitch, B);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_grid_rest_features: launch failed");
+  return 0;
+}
+
+int dcd_policy_wide_packed_heads_floats(const DcdStudentNet* net) { return check_wide_net(net, "dcd_policy_wide_packed_heads_floats") ? 0 : wide_floats(net->NA); }
+
+int dcd_policy_wide_pack_heads(const DcdStudentNet* net, float* packed, void* stream) {
+  if (check_wide_net(net, "dcd_policy_wide_pack_heads")) return 1;
+  if (!packed) return dcd::fail("dcd_policy_wide_pack_heads: NULL output");
+  hipLaunchKernelGGL(wide_heads_pack_kernel, dim3((wide_floats(net->NA) + PB - 1) / PB), dim3(PB), 0, (hipStream_t)stream, *net, packed);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_wide_pack_heads: launch failed");
+  return 0;
+}
+
+int dcd_policy_wide_cell_heads(const DcdStudentNet* net, const float* packed, const float* gates, const float* hc_in, const float* masks,
+                               float* hc_out, float* value, int64_t* action, float* action_log_prob, float* action_log_dist, float* u_out,
+                               uint32_t seed, uint32_t counter, const uint32_t* counter_base, int64_t env_index_base, int32_t deterministic,
+                               int32_t B, void* stream) {
+  if (check_wide_net(net, "dcd_policy_wide_cell_heads")) return 1;
+  if (!packed || !gates || !hc_in || !masks || !hc_out || !value || !action || !action_log_prob || !action_log_dist || B <= 0)
+    return dcd::fail("dcd_policy_wide_cell_heads: NULL pointer or B <= 0");
+  CellArgs a{gates, hc_in, masks, hc_out, value, action, action_log_prob, action_log_dist, u_out, seed, counter, counter_base, env_index_base,
+             deterministic, B};
+  const size_t lds = sizeof(float) * ((size_t)wide_floats(net->NA) + CW * MAXH * EW + CW * EW * 64);
+  static bool attr_set = false;
+  if (!attr_set) {
+    const size_t cap = sizeof(float) * ((size_t)wide_floats(WMAXA - 1) + CW * MAXH * EW + CW * EW * 64);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_cell_heads_kernel<MAXH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess)
+      return dcd::fail("dcd_policy_wide_cell_heads: cannot reserve %zu bytes of LDS", cap);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wide_cell_heads_kernel<MAXH>, dim3((B + HE - 1) / HE), dim3(CB), lds, (hipStream_t)stream, *net, packed, a);
+  if (hipGetLastError() != hipSuccess) return dcd::fail("dcd_policy_wide_cell_heads: launch failed");
+  return 0;
+}
+
 int dcd_grid_tile_gemm(const float* rows, const float* wp, const int32_t* tile_pos, const int32_t* n_used, float* y, int32_t n_tiles,
                        int32_t F, int32_t G, void* stream) {
   if (!rows || !wp || !tile_pos || !n_used || !y || n_tiles <= 0) return dcd::fail("dcd_grid_tile_gemm: NULL pointer or no tiles");

@@ -300,8 +300,32 @@ class GridActor:
         self.gates = torch.empty((self.B, 4 * self.H), device=dev)
         self.w_t = torch.zeros((self.KP, 4 * self.H), device=dev)
         self.bias = torch.empty((4 * self.H,), device=dev)
+        # fused step (`act_storage`): heads of one Linear + Tanh each, < 192 actions, H = 256 -> everything after the carried
+        # projection is two HIP kernels around one GEMM and lands in the storage; else `act` returns tensors as the module does
+        self.fused_heads = self.heads_supported(net)
+        self.seed, self.env_index_base = 0, 0
+        if self.fused_heads:
+            a1, a2, c1, c2 = net.actor[0][0], net.actor[1].linear, net.critic[0][0], net.critic[1]
+            self._params += [a1.weight, a1.bias, a2.weight, a2.bias, c1.weight, c1.bias, c2.weight, c2.bias]
+            self._dims.update(A1=a1.out_features, C1=c1.out_features, NA=a2.out_features)
+            self.KR = (E + self.Z + self.H + 1 + 31) // 32 * 32       # operand row of everything but the image (+ the bias column)
+            self.x_rest = torch.zeros((self.B, self.KR), device=dev)
+            self.w_rest = torch.zeros((self.KR, 4 * self.H), device=dev)
+            self.counter_base = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.packed = None
         self._struct, self._w_version = None, None
         self.refresh()
+
+    @staticmethod
+    def heads_supported(net):
+        try:
+            if len(net.actor[0]) != 2 or len(net.critic[0]) != 2 or net.rnn.rnn.hidden_size != 256:
+                return False
+            a1, a2, c1, c2 = net.actor[0][0], net.actor[1].linear, net.critic[0][0], net.critic[1]
+            return (a1.out_features <= 32 and c1.out_features <= 32 and a2.out_features < 192 and c2.out_features == 1
+                    and a2.in_features == a1.out_features and c2.in_features == c1.out_features)
+        except (AttributeError, IndexError, TypeError):
+            return False
 
     @staticmethod
     def supported(net):
@@ -329,7 +353,7 @@ class GridActor:
     def refresh(self):
         l = self._lstm
         ver = tuple(p._version for p in (l.weight_ih_l0, l.weight_hh_l0, l.bias_ih_l0, l.bias_hh_l0)) + \
-            tuple(p.data_ptr() for p in self._params)
+            tuple((p.data_ptr(), p._version) for p in self._params)
         if ver == self._w_version:
             return
         with torch.no_grad():
@@ -342,11 +366,22 @@ class GridActor:
                 self.wp = torch.empty((P, F, G), device=self.w_t.device)
             self.wp.copy_(l.weight_ih_l0[:, :F * P].view(G, F, P).permute(2, 1, 0))             # [P, F, 4H]: per-position blocks
         s = StudentNet()
-        for name, p in zip(("conv_w", "conv_b", "embed_w", "embed_b"), self._params):
+        names = ("conv_w", "conv_b", "embed_w", "embed_b", "actor_w1", "actor_b1", "actor_w2", "actor_b2", "critic_w1", "critic_b1",
+                 "critic_w2", "critic_b2")
+        for name, p in zip(names, self._params):
             setattr(s, name, ptr(p.detach(), torch.float32, name=name).value)
         for k, v in self._dims.items():
             setattr(s, k, v)
         self._struct, self._w_version = s, ver
+        if self.fused_heads:
+            FP = self.K - self.H - self.Z - self._dims["E"]
+            n_rest = self.K - FP                                          # E + Z + H rows of the stacked weight
+            with torch.no_grad():
+                self.w_rest[:n_rest].copy_(self.w_t[FP:self.K])
+                self.w_rest[n_rest].copy_(self.bias)                      # multiplied by the operand's constant-1 column
+            if self.packed is None:
+                self.packed = torch.empty((lib().dcd_policy_wide_packed_heads_floats(C.byref(s)),), device=self.w_t.device)
+            check(lib().dcd_policy_wide_pack_heads(C.byref(s), ptr(self.packed), stream_ptr()))
 
     # ---- incremental acting: the image part of the projection is carried from step to step ------------------------
     def begin_episode(self):
@@ -426,6 +461,7 @@ class GridActor:
                            err=torch.zeros(1, **i32), xp=torch.empty((B, G), device=dev))
         return self._d
 
+    @torch.no_grad()
     def _carry_projection_device(self, image, prev_image):
         """`_carry_projection` for raw u8 images with nothing read back: `dcd_grid_delta_rows` finds each env's changed
         cell, bins the (env, conv position) pairs by position in env order and writes their feature differences as
@@ -474,6 +510,38 @@ class GridActor:
             raise DcdHipError(f"carried teacher projection: error word {e} (1: more than one cell of an observation changed in "
                               "one step, 2: tile table overflow) - the rollout's projections are invalid; DCD_INCREMENTAL_ACT=0 "
                               "multiplies the dense operand instead")
+
+    # ---- the whole step into the storage: carried projection, rest operand, ONE GEMM, cell + heads + draw -------------------
+    def begin_rollout(self, num_steps):
+        """Once per teacher rollout, OUTSIDE any capture: weights of the last optimiser step, fresh Philox counters."""
+        self.refresh()
+        if self.fused_heads:
+            self.counter_base.add_(int(num_steps))
+
+    @torch.no_grad()
+    def act_storage(self, st, step, deterministic=False):
+        """`agent.act(obs[step], h[step], masks[step])` + `storage.insert_policy(...)` (adversarial_runner.py:506-517) of a
+        teacher step on u8 rollout buffers, nothing read back: writes value_preds[step], actions[step], action_log_probs[step],
+        action_log_dist[step], recurrent_hidden_states[step+1].  Needs `fused_heads` and `device_carry_supported`."""
+        L, B, H, s = lib(), self.B, self.H, self._struct
+        img8 = st.obs_u8["image"]
+        self._carry_projection_device(img8[step], img8[step - 1] if step else None)
+        scalar = st._obs["time_step"][step] if "time_step" in st._obs else st._obs["direction"][step]
+        z = st._obs["random_z"][step] if self.Z else None
+        hc_in, masks = st.recurrent_hidden_states[step], st.masks[step]
+        check(L.dcd_policy_grid_rest_features(C.byref(s), ptr(scalar, torch.float32, B, "scalar"),
+                                              ptr(z, torch.float32, B * self.Z, "random_z") if z is not None else None, C.c_int32(self.Z),
+                                              ptr(hc_in, torch.float32, B * 2 * H, "hc_in"), ptr(masks, torch.float32, B, "masks"),
+                                              ptr(self.x_rest), C.c_int32(self.KR), C.c_int32(B), stream_ptr()))
+        torch.addmm(self._xp_img, self.x_rest, self.w_rest, out=self.gates)
+        NA = self._dims["NA"]
+        check(L.dcd_policy_wide_cell_heads(C.byref(s), ptr(self.packed), ptr(self.gates), ptr(hc_in), ptr(masks),
+                                           ptr(st.recurrent_hidden_states[step + 1], torch.float32, B * 2 * H, "hc_out"),
+                                           ptr(st.value_preds[step], torch.float32, B, "value"), ptr(st.actions[step], torch.int64, B, "action"),
+                                           ptr(st.action_log_probs[step], torch.float32, B, "log_prob"),
+                                           ptr(st.action_log_dist[step], torch.float32, B * NA, "log_dist"), None,
+                                           C.c_uint32(self.seed), C.c_uint32(step & 0xFFFFFFFF), C.c_void_p(self.counter_base.data_ptr()),
+                                           C.c_int64(self.env_index_base), C.c_int32(int(deterministic)), C.c_int32(B), stream_ptr()))
 
     def act(self, obs, hc_in, masks, deterministic=False, prev_image=None, first=False):
         """`first` / `prev_image` (the previous step's image of the same episode) enable the carried projection

@@ -127,6 +127,7 @@ class AdversarialRunner:
         # rollouts advance in lock-step, ONE env-step launch for both (dcd_mg_step_pair) on two copies of the levels.
         self.pair_rollouts = os.environ.get("DCD_PAIR_ROLLOUT", "1") != "0" and self.device.type == "cuda"
         self.pair_policy_launches = self.pair_rollouts and os.environ.get("DCD_PAIR_POLICY", "1") != "0"
+        self.fuse_teacher_step = os.environ.get("DCD_FUSED_TEACHER", "1") != "0"
         # DCD_U8_OBS=1 (default): the students' rollout buffers hold the RAW observation bytes (76 B per env-step instead of
         # 304 B of preprocessed fp32); the fused policy step reads them, fp32 views are derived for the PPO batch
         if os.environ.get("DCD_U8_OBS", "1") != "0" and self.device.type == "cuda":
@@ -400,9 +401,9 @@ class AdversarialRunner:
         # the carried projection on raw u8 observations reads nothing back: the whole constructive episode is one graph
         device_resident = (ga is not None and self.use_hip_graphs and st.obs_u8 is not None
                            and ga.device_carry_supported(st.obs_u8["image"][0]))
+        if ga is not None:
+            ga.begin_rollout(num_steps)                                  # optimiser steps / Philox counters: OUTSIDE the capture
         if self.graph_pytorch_nets or device_resident:
-            if ga is not None:
-                ga.refresh()                                             # optimiser steps are picked up OUTSIDE the capture
             self._graphed(("teacher", id(agent), num_steps, bool(agent.actor_critic.random)), num_steps, body)
         else:
             body(0, num_steps)
@@ -418,6 +419,9 @@ class AdversarialRunner:
         if ga is False:
             from dcd_hip.policy import GridActor
             ga = GridActor.try_create(agent.actor_critic, self.args.num_processes) if self.device.type == "cuda" else None
+            if ga is not None:
+                ga.seed = (self.args.seed * 2654435761 + 977) & 0xFFFFFFFF
+                ga.env_index_base = getattr(self.venv, "env_index_base", 0)
             agent._grid_actor = ga
         if ga is not None and agent.actor_critic.random:
             return None
@@ -434,9 +438,16 @@ class AdversarialRunner:
             grid_actor.refresh()
             if t0 == 0:
                 grid_actor.begin_episode()
+        fused_step = (grid_actor is not None and grid_actor.fused_heads and st.obs_u8 is not None and self.fuse_teacher_step
+                      and grid_actor._incremental and grid_actor.device_carry_supported(st.obs_u8["image"][0]))
         for step in range(t0, t1):
+            if fused_step:                                   # carried projection + rest operand + GEMM + cell / heads / draw -> storage
+                grid_actor.act_storage(st, step)
+                action = st.actions[step]
             with torch.no_grad():
-                if grid_actor is not None:
+                if fused_step:
+                    pass
+                elif grid_actor is not None:
                     img = st.obs_u8["image"] if st.obs_u8 is not None else st._obs["image"]
                     value, action, log_dist, hxs = grid_actor.act(
                         st.rollout_obs(step), st.recurrent_hidden_states[step], st.masks[step], first=step == 0,
@@ -444,8 +455,10 @@ class AdversarialRunner:
                 else:
                     value, action, log_dist, hxs = agent.act(st.get_obs(step), st.get_recurrent_hidden_state(step),
                                                              st.masks[step])
-                log_prob = log_dist.gather(-1, action) if self.is_discrete_adversary_env_actions else log_dist
-            st.insert_policy(hxs, action, log_prob, log_dist, value)
+                if not fused_step:
+                    log_prob = log_dist.gather(-1, action) if self.is_discrete_adversary_env_actions else log_dist
+            if not fused_step:
+                st.insert_policy(hxs, action, log_prob, log_dist, value)
             out = st.adversary_obs_out(step + 1)
             out["done"] = self._done_buf
             venv.step_adversary_device(action.view(-1), out)

@@ -423,6 +423,27 @@ int dcd_policy_cell_heads(const DcdStudentNet* net, const float* packed, const f
                           float* action_log_dist, float* u_out, uint32_t seed, uint32_t counter,
                           const uint32_t* counter_base, int64_t env_index_base, int32_t deterministic, int32_t B, void* stream);
 
+/* The teacher's rollout step around its GEMMs (`act` + the policy half of storage.insert for a recurrent grid-observing
+ * network with up to 191 actions, one Linear + Tanh per head: multigrid_models.py:109-167, util/make_agent.py:22-36):
+ *   dcd_policy_grid_rest_features   x[b] = [scalar_embed(one_hot(scalar[b])) | z[b] | h[b]*masks[b] | 1 | 0...], x float[B,x_pitch],
+ *                                   x_pitch >= E + z_dim + H + 1: everything of the LSTM input but the conv features (whose
+ *                                   projection is carried, dcd_grid_delta_rows); the 1 multiplies the bias row of the caller's
+ *                                   stacked weight, so gates = xp_image + x @ W needs no bias operand;
+ *   dcd_policy_wide_pack_heads      head weights re-laid out (float[dcd_policy_wide_packed_heads_floats(net)]; after every
+ *                                   optimiser step);
+ *   dcd_policy_wide_cell_heads      dcd_policy_cell_heads for NA < 192: a whole wave per env for the second layer, the
+ *                                   log-softmax and the inverse-CDF draw (cumulative probabilities in index order by wave
+ *                                   scans; same Philox keying as the students). */
+int dcd_policy_grid_rest_features(const DcdStudentNet* net, const float* scalar, const float* z, int32_t z_dim, const float* hc,
+                                  const float* masks, float* x, int32_t x_pitch, int32_t B, void* stream);
+int dcd_policy_wide_packed_heads_floats(const DcdStudentNet* net);
+int dcd_policy_wide_pack_heads(const DcdStudentNet* net, float* packed, void* stream);
+int dcd_policy_wide_cell_heads(const DcdStudentNet* net, const float* packed, const float* gates, const float* hc_in,
+                               const float* masks, float* hc_out, float* value, int64_t* action, float* action_log_prob,
+                               float* action_log_dist, float* u_out, uint32_t seed, uint32_t counter,
+                               const uint32_t* counter_base, int64_t env_index_base, int32_t deterministic, int32_t B,
+                               void* stream);
+
 /* Two students per launch (PAIRED: the protagonist's and the antagonist's `act` at the same step of their lock-step rollouts,
  * adversarial_runner.py:709-733 + 506-517): every pointer of dcd_policy_features_u8 / dcd_policy_cell_heads once per agent.
  * The two networks must have one geometry.  The caller forms both gates tensors between the two calls (one batched GEMM). */

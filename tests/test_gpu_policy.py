@@ -539,3 +539,109 @@ def test_paired_student_actors_equal_two_single_actors():
         for k in ("value_preds", "actions", "action_log_probs", "action_log_dist", "recurrent_hidden_states"):
             assert torch.equal(getattr(a, k), getattr(b, k)), k
     assert not torch.equal(sp[0].actions, sp[1].actions)             # two different policies / streams
+
+
+def _teacher_setup(B):
+    from tests.test_gpu_runner import build, make_args
+    runner, venv = build(make_args(ued_algo="paired", num_processes=B))
+    teacher = runner.agents["adversary_env"]
+    with torch.no_grad():                                            # un-degenerate the policy head (init gain 0.01)
+        teacher.algo.actor_critic.actor[1].linear.weight.mul_(80.0)
+        teacher.algo.actor_critic.actor[1].linear.bias.add_(0.3 * torch.randn_like(teacher.algo.actor_critic.actor[1].linear.bias))
+    runner._teacher_rollout(teacher, runner.adversary_env_rollout_steps)
+    return runner, venv, teacher
+
+
+def _wide_heads(ga, gates, hc, masks, deterministic, counter=0, seed=3):
+    import ctypes as C
+    from dcd_hip import check, lib, ptr, stream_ptr
+    B, NA = ga.B, ga._dims["NA"]
+    out = dict(hc=torch.zeros(B, 512, device=DEV), value=torch.zeros(B, 1, device=DEV), action=torch.zeros(B, 1, dtype=torch.int64, device=DEV),
+               logp=torch.zeros(B, 1, device=DEV), log_dist=torch.zeros(B, NA, device=DEV), u=torch.zeros(B, device=DEV))
+    check(lib().dcd_policy_wide_cell_heads(C.byref(ga._struct), ptr(ga.packed), ptr(gates), ptr(hc), ptr(masks), ptr(out["hc"]), ptr(out["value"]),
+                                           ptr(out["action"], torch.int64), ptr(out["logp"]), ptr(out["log_dist"]), ptr(out["u"]),
+                                           C.c_uint32(seed), C.c_uint32(counter), None, C.c_int64(500), C.c_int32(int(deterministic)),
+                                           C.c_int32(B), stream_ptr()))
+    torch.cuda.synchronize()
+    return out
+
+
+def test_wide_cell_heads_match_the_teacher_module_and_sample_their_own_distribution():
+    """dcd_policy_wide_cell_heads (169 actions) on the gates of a real teacher step: (h', c'), value and normalised logits
+    within 3e-6 of the PyTorch cell + heads, arg max equal where unambiguous, log-prob = log_dist[action]; sampled actions are
+    the inverse CDF (index order) of the kernel's own distribution at its own uniform; frequencies over 32k draws |z| < 5."""
+    from dcd_hip.policy import GridActor
+    B = 256
+    runner, venv, teacher = _teacher_setup(B)
+    net, st = teacher.algo.actor_critic, teacher.storage
+    ga = GridActor(net, B)
+    assert ga.fused_heads and ga._dims["NA"] == 169
+    for step in (0, 5, 26):
+        obs, hc, masks = st.rollout_obs(step), st.recurrent_hidden_states[step], st.masks[step]
+        with torch.no_grad():
+            v0, a0, l0, (h0, c0) = ga._act_dense(obs, hc, masks, deterministic=True)
+        out = _wide_heads(ga, ga.gates, hc, masks, deterministic=True)
+        assert (out["hc"][:, :256] - h0).abs().max().item() <= ATOL and (out["hc"][:, 256:] - c0).abs().max().item() <= ATOL
+        assert (out["value"] - v0).abs().max().item() <= ATOL
+        assert (out["log_dist"] - l0).abs().max().item() <= 2e-5       # logits O(1) after the head rescale: 1e-5 relative
+        top2 = l0.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert clear.float().mean().item() > 0.9 and torch.equal(out["action"][clear], a0[clear])
+        assert torch.equal(out["logp"], out["log_dist"].gather(-1, out["action"]))
+        smp = _wide_heads(ga, ga.gates, hc, masks, deterministic=False, counter=step)
+        p = smp["log_dist"].double().exp().cpu().numpy()
+        cum = np.cumsum(p, axis=1)
+        a = smp["action"].cpu().numpy()[:, 0]
+        u = smp["u"].double().cpu().numpy()
+        lo = np.where(a > 0, cum[np.arange(B), np.maximum(a - 1, 0)], 0.0)
+        assert (u >= lo - 2e-6).all() and (u < cum[np.arange(B), a] + 2e-6).all() and 0.4 < u.mean() < 0.6
+        assert torch.equal(smp["logp"], smp["log_dist"].gather(-1, smp["action"]))
+        assert len(np.unique(a)) > 20                                 # a spread-out 169-way distribution, not one action
+    # one env replicated: frequencies
+    gates1 = ga.gates[:1].expand(B, -1).contiguous()
+    hc1, m1 = st.recurrent_hidden_states[26][:1].expand(B, -1).contiguous(), st.masks[26][:1].expand(B, -1).contiguous()
+    counts = np.zeros(169)
+    for k in range(128):
+        o = _wide_heads(ga, gates1, hc1, m1, deterministic=False, counter=k)
+        counts += np.bincount(o["action"].cpu().numpy()[:, 0], minlength=169)
+    p = o["log_dist"][0].double().exp().cpu().numpy()
+    n = counts.sum()
+    z = (counts - n * p) / np.sqrt(n * p * (1 - p) + 1e-12)
+    assert np.abs(z).max() < 5.0
+    venv.close()
+
+
+def test_grid_actor_act_storage_equals_act_plus_insert():
+    """GridActor.act_storage (carried projection + dcd_policy_grid_rest_features + one GEMM + dcd_policy_wide_cell_heads, straight into
+    the storage) against GridActor.act (same carried projection, PyTorch cell / heads) + insert_policy over a real 27-step
+    teacher episode, deterministic: value / log-dist / log-prob / hidden state within 2e-5 of scale, actions equal where the
+    arg max is unambiguous; the sampled path fills valid actions and the log-prob of the action it drew."""
+    from dcd_hip.policy import GridActor
+    B = 96
+    runner, venv, teacher = _teacher_setup(B)
+    net, st = teacher.algo.actor_critic, teacher.storage
+    T = runner.adversary_env_rollout_steps
+    ga, gf = GridActor(net, B), GridActor(net, B)
+    ga.begin_episode(); gf.begin_episode()
+    gf.begin_rollout(T)
+    keep = {k: getattr(st, k).clone() for k in ("value_preds", "actions", "action_log_probs", "action_log_dist", "recurrent_hidden_states")}
+    img8 = st.obs_u8["image"]
+    for step in range(T):
+        hc, masks = keep["recurrent_hidden_states"][step], st.masks[step]
+        st.recurrent_hidden_states[step].copy_(hc)
+        with torch.no_grad():
+            v, a, l, (h, c) = ga.act(st.rollout_obs(step), hc, masks, deterministic=True, first=step == 0,
+                                     prev_image=img8[step - 1] if step else None)
+        gf.act_storage(st, step, deterministic=True)
+        for name, x, y in (("value", v, st.value_preds[step]), ("log_dist", l, st.action_log_dist[step]),
+                           ("h", h, st.recurrent_hidden_states[step + 1][:, :256]), ("c", c, st.recurrent_hidden_states[step + 1][:, 256:])):
+            assert (x - y).abs().max().item() <= 2e-5 * max(x.abs().max().item(), 1.0), (step, name)
+        top2 = l.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+        assert torch.equal(st.actions[step][clear], a[clear])
+        assert torch.equal(st.action_log_probs[step], st.action_log_dist[step].gather(-1, st.actions[step]))
+    gf.check_carry_errors()
+    gf.act_storage(st, T - 1)                                          # sampled
+    assert st.actions[T - 1].min() >= 0 and st.actions[T - 1].max() < 169
+    assert torch.equal(st.action_log_probs[T - 1], st.action_log_dist[T - 1].gather(-1, st.actions[T - 1]))
+    venv.close()
