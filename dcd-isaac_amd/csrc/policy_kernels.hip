@@ -719,6 +719,8 @@ __global__ void __launch_bounds__(CB) wide_cell_heads_kernel(DcdStudentNet n, co
 // 4 waves as 2 x 2, each 64 x 64 = four 32 x 32 accumulators (4 independent MFMAs per 4 LDS reads).  Tiles past the
 // last bin (n_used, written by grid_delta_rows_kernel) exit at once: the padding of the fixed-shape launch costs nothing.
 // Replaces {index_select of 456 weight blocks (234 MB) + rocBLAS batched GEMM}: 308 -> see DESIGN.md §3.
+// Tried and dropped: K in two halves of 64 (67 KB of LDS -> two workgroups per CU, second half prefetched into registers
+// under the first half's MFMAs): 145 -> 181 us per step, same-box A/B.
 constexpr int GA_P = 132;          // LDS pitch of the A tile (floats)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

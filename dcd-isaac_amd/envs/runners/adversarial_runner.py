@@ -438,6 +438,9 @@ class AdversarialRunner:
             grid_actor.refresh()
             if t0 == 0:
                 grid_actor.begin_episode()
+        st.rewards[t0:t1].zero_()                            # a constructive step pays nothing; no time limits (:497-592 with is_env)
+        st.bad_masks[t0 + 1:t1 + 1].fill_(1.0)
+        st.cliffhanger_masks[t0 + 1:t1 + 1].fill_(1.0)
         fused_step = (grid_actor is not None and grid_actor.fused_heads and st.obs_u8 is not None and self.fuse_teacher_step
                       and grid_actor._incremental and grid_actor.device_carry_supported(st.obs_u8["image"][0]))
         for step in range(t0, t1):
@@ -462,10 +465,7 @@ class AdversarialRunner:
             out = st.adversary_obs_out(step + 1)
             out["done"] = self._done_buf
             venv.step_adversary_device(action.view(-1), out)
-            st.rewards[step].zero_()
-            st.masks[step + 1].copy_((1 - self._done_buf.float()).view(B, 1))
-            st.bad_masks[step + 1].fill_(1.0)
-            st.cliffhanger_masks[step + 1].fill_(1.0)
+            st.masks[step + 1].copy_(self._done_buf.view(B, 1) == 0)      # 1 - done (:520-524); the constant rows: once, above
             st.advance()
 
     def _resample_finished_levels(self, st, step, level_sampler, rollout_info):
