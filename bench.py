@@ -384,14 +384,19 @@ def end_to_end_leg(B, T, device, updates):
     runner._paired_student_rollouts((agents[0], agents[1]), T, track_seeds=False)
     torch.cuda.synchronize()
     roll = (time.perf_counter() - t0) / 2                          # per student rollout of B x T env-steps
+    t0 = time.perf_counter()
+    runner._teacher_rollout(agents[2], runner.adversary_env_rollout_steps)  # 27 constructive steps, teacher policy in the loop, one graph
+    torch.cuda.synchronize()
+    teacher = time.perf_counter() - t0
     venv.close()
-    return {"S_roll_env_steps_per_s": B * T / roll, "student_rollout_ms": roll * 1e3,
+    return {"S_roll_env_steps_per_s": B * T / roll, "student_rollout_ms": roll * 1e3, "teacher_rollout_ms": teacher * 1e3,
             "S_train_sps_reference_formula": B * T / dt,                    # train.py:184 counts one student rollout per update
             "S_train_true_env_steps_per_s": (2 * B * T + B * 27) / dt, "seconds_per_update": dt, "updates_timed": updates,
             "seconds_each_update": [round(x, 4) for x in per_update],
             "what": "AdversarialRunner.run(), PAIRED, LSTM-256 students (433 953 params) + recurrent teacher (22 502 732 params), "
                     "PPO 5 epochs x 1 minibatch, fp32; student rollouts: both students in lock-step (one env-step launch for both), fused HIP "
-                    "policy step on raw u8 observations, one HIP graph per rollout pair; "
+                    "policy step on raw u8 observations (both students per launch), one HIP graph per rollout pair; teacher rollout: carried input "
+                    "projection (fp32 MFMA tile product) + fused cell / 169-way heads, one HIP graph; "
                     "PPO: PyTorch-ROCm with the masked LSTM as one autograd node over HIP pointwise kernels"}
 
 

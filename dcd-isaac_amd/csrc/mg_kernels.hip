@@ -417,6 +417,9 @@ __device__ __forceinline__ void emit_grid(const uint8_t* lds, const Luts& lut, u
     }
   }
   if (u8) {
+    // (one byte per store; assembling dwords from pairs of 24-bit LUT entries — a quarter of the stores and loop trips —
+    // measured the same, streaming stores slower: of a teacher step's 6.0 us, 2.1 are this image's 2.8 MB, 0.35 random_z's
+    // 0.8 MB, 3.2 the launch with no outputs at all — `tools/time_teacher_steps.py`, round 2)
 #pragma unroll 4
     for (int f = tid; f < n * G; f += NT) {
       const int r = f / G, el = f - r * G, cell = el / 3, c = el - cell * 3, x = cell / S, y = cell - x * S;
