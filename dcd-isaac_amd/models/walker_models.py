@@ -1,5 +1,6 @@
-"""BipedalWalker student policy (reference: models/walker_models.py:113-167 BipedalWalkerStudentPolicy, :345-376 MLPBase,
-:49-67 DiagGaussian; BASELINE config 4).  PyTorch-ROCm like the MultiGrid nets; parameter names and
+"""BipedalWalker student policy and level-builder policy (reference: models/walker_models.py:113-167
+BipedalWalkerStudentPolicy, :170-257 BipedalWalkerAdversaryPolicy, :345-376 MLPBase, :49-67 DiagGaussian; BASELINE config 4,
+SURVEY §8f-4).  PyTorch-ROCm like the MultiGrid nets; parameter names and
 initialisers follow the reference (same seed -> same weights, its checkpoints load): two tanh MLP towers of width 64 for
 actor and critic (orthogonal, gain sqrt 2), a linear value head, a diagonal Gaussian with a state-independent log-std.
 The feed-forward configuration every shipped BipedalWalker config uses; the optional GRU of the reference's base is the
@@ -97,5 +98,55 @@ class BipedalWalkerStudentPolicy(DeviceAwareModule):
 
     def evaluate_actions(self, inputs, rnn_hxs, masks, action):
         value, feats, rnn_hxs = self.base(inputs, rnn_hxs, masks)
+        dist = self.dist(feats)
+        return value, dist.log_probs(action), dist.entropy().mean(), rnn_hxs
+
+
+class BipedalWalkerAdversaryPolicy(DeviceAwareModule):
+    """The level builder (walker_models.py:170-257): the design vector, random_z and the time step concatenated into the same
+    two-tower MLP, a diagonal Gaussian over the design parameters.  The continuous form every shipped config uses; the
+    reference's `editor=True` branch builds a Python list of Categoricals that its own `act` cannot sample from, so it is
+    not reproduced.  Kept quirks: `act` squashes the sampled action with tanh and returns the Gaussian log-prob OF THE
+    SQUASHED action (:236-238); the random builder draws from numpy's global stream (:222)."""
+
+    def __init__(self, observation_space, action_space, editor=False, random=False, base_kwargs=None):
+        super().__init__()
+        if editor:
+            raise NotImplementedError("BipedalWalkerAdversaryPolicy(editor=True): not functional in the reference either")
+        self.random = random
+        self.design_dim = observation_space["image"].shape[0]
+        self.random_z_dim = observation_space["random_z"].shape[0]
+        self.base = MLPBase(self.design_dim + self.random_z_dim + 1, **(base_kwargs or {}))
+        self.editor = False
+        self.action_dim = action_space.shape[0]
+        self.dist = DiagGaussian(self.base.output_size, self.action_dim)
+
+    @property
+    def is_recurrent(self):
+        return self.base.is_recurrent
+
+    @property
+    def recurrent_hidden_state_size(self):
+        return self.base.recurrent_hidden_state_size
+
+    def preprocess(self, inputs):
+        return torch.cat([inputs["image"], inputs["random_z"], inputs["time_step"]], dim=1)
+
+    def act(self, inputs, rnn_hxs, masks, deterministic=False):
+        x = self.preprocess(inputs)
+        if self.random:
+            n = x.shape[0]
+            action = torch.tensor(np.random.uniform(-1, 1, n), device=x.device).reshape(-1, 1)
+            return torch.zeros(n, 1, device=x.device), action, torch.ones(n, self.action_dim, device=x.device), rnn_hxs
+        value, feats, rnn_hxs = self.base(x, rnn_hxs, masks)
+        dist = self.dist(feats)
+        action = torch.tanh(dist.mode() if deterministic else dist.sample())
+        return value, action, dist.log_probs(action), rnn_hxs
+
+    def get_value(self, inputs, rnn_hxs, masks):
+        return self.base(self.preprocess(inputs), rnn_hxs, masks)[0]
+
+    def evaluate_actions(self, inputs, rnn_hxs, masks, action):
+        value, feats, rnn_hxs = self.base(self.preprocess(inputs), rnn_hxs, masks)
         dist = self.dist(feats)
         return value, dist.log_probs(action), dist.entropy().mean(), rnn_hxs

@@ -504,6 +504,32 @@ def gen_f4_nets():
     print("f4_nets.npz", len(out))
 
 
+def gen_f4_adv():
+    """models/walker_models.py:170-257 BipedalWalkerAdversaryPolicy (the level builder of BASELINE config 4; the continuous,
+    non-editor form every shipped config uses): initial weights from a fixed seed, deterministic act (incl. the reference's
+    log-prob of the SQUASHED action), get_value, evaluate_actions on fixed inputs."""
+    from models.walker_models import BipedalWalkerAdversaryPolicy
+    rng = np.random.default_rng(21)
+    obs = {"image": Box((8,)), "random_z": Box((10,)), "time_step": Box((1,))}
+    act = Box((8,))
+    torch.manual_seed(0)
+    net = BipedalWalkerAdversaryPolicy(obs, act)
+    x = {"image": rng.standard_normal((5, 8)).astype(np.float32), "random_z": rng.random((5, 10)).astype(np.float32),
+         "time_step": np.arange(5, dtype=np.float32).reshape(5, 1)}
+    a = np.tanh(rng.standard_normal((5, 8))).astype(np.float32)
+    xt = {k: torch.from_numpy(v) for k, v in x.items()}
+    with torch.no_grad():
+        v, lp, ent, _ = net.evaluate_actions(xt, None, None, torch.from_numpy(a))
+        det = net.act(xt, None, None, deterministic=True)
+        gv = net.get_value(xt, None, None)
+    out = {f"w_{k}": p.detach().numpy().copy() for k, p in net.state_dict().items()}
+    out.update({f"x_{k}": v_ for k, v_ in x.items()})
+    out.update(a=a, value=v.numpy(), logp=lp.numpy(), ent=np.array(ent.item()), det_value=det[0].numpy(), det_action=det[1].numpy(),
+               det_logp=det[2].numpy(), get_value=gv.numpy())
+    np.savez_compressed(os.path.join(OUT, "f4_adv.npz"), **out)
+    print("f4_adv.npz", len(out))
+
+
 if __name__ == "__main__":
     import numpy.ma  # noqa: F401  (must be imported BEFORE the alias shims: numpy 2 uses np.bool as a dtype there)
     import matplotlib
@@ -511,6 +537,6 @@ if __name__ == "__main__":
     import matplotlib.pyplot  # noqa: F401  (envs/box2d/bezier.py imports it at module level)
     install_shims()
     torch.set_num_threads(1)
-    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy", "popart", "bezier", "f4_nets"]     # name the sets to (re)generate
+    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy", "popart", "bezier", "f4_nets", "f4_adv"]     # name the sets to (re)generate
     for name in todo:
         globals()["gen_" + name]()
