@@ -362,14 +362,20 @@ class RolloutStorage:
             for i, t in enumerate(done_steps[:-1]):
                 yield b, " ".join(str(a) for a in acts[t:done_steps[i + 1], b])
 
-    def _action_complexity(self, per_env):
+    def action_complexity_inputs(self):
+        """Host copies of what the action complexity reads (actions, masks): taken when the rollout is complete, so that the
+        LZ76 pass itself can run later, beside the PPO updates (which rewrite masks[0] in after_update)."""
+        import numpy as np
+        return (np.ascontiguousarray(self.actions[:, :, 0].cpu().numpy().astype(np.int64)),
+                np.ascontiguousarray(self.masks[:, :, 0].cpu().numpy().astype(np.float32)))
+
+    def _action_complexity(self, per_env, inputs=None):
         """dcd_action_complexity (csrc/host_utils.cpp): the per-character LZ76 loop in C, on host copies of the
         action and mask buffers (1M characters per rollout at 4096 envs: 0.37 s in Python)."""
         import ctypes as C
         import numpy as np
         from dcd_hip import check, lib
-        acts = np.ascontiguousarray(self.actions[:, :, 0].cpu().numpy().astype(np.int64))
-        masks = np.ascontiguousarray(self.masks[:, :, 0].cpu().numpy().astype(np.float32))
+        acts, masks = inputs if inputs is not None else self.action_complexity_inputs()
         T, B = acts.shape
         total, n = C.c_double(0), C.c_int64(0)
         env = np.zeros(B, np.float32) if per_env else None
@@ -378,8 +384,8 @@ class RolloutStorage:
                                           env.ctypes.data_as(C.c_void_p) if per_env else None))
         return total.value, n.value, env
 
-    def get_action_complexity(self):
-        total, n, _ = self._action_complexity(False)
+    def get_action_complexity(self, inputs=None):
+        total, n, _ = self._action_complexity(False, inputs)
         return total / max(n, 1)
 
     def get_batched_action_complexity(self):

@@ -59,7 +59,7 @@ class AdversarialRunner:
             self.world_size = dist.get_world_size(process_group)
         self.venv = venv
         self.ued_venv = venv if ued_venv is None else ued_venv
-        self._pending_updates, self._update_streams = [], []
+        self._pending_updates, self._update_streams, self._deferred_host = [], [], []
         self._concurrent_updates = (self.world_size == 1 and os.environ.get("DCD_CONCURRENT_PPO", "1") != "0")
         self.is_discrete_actions = is_discrete_actions(self.venv)
         self.is_discrete_adversary_env_actions = is_discrete_actions(self.venv, adversary=True)
@@ -751,7 +751,10 @@ class AdversarialRunner:
             if level_sampler and update_level_sampler:
                 level_sampler.after_update()                              # sampler bookkeeping: independent of the PPO result
             if args.log_action_complexity:
-                rollout_info["action_complexity"] = st.get_action_complexity()
+                if self._concurrent_updates:              # host-side LZ76 pass (5 ms per student): runs under the PPO updates
+                    self._deferred_host.append((rollout_info, st, st.action_complexity_inputs()))
+                else:
+                    rollout_info["action_complexity"] = st.get_action_complexity()
         return rollout_info
 
     # ---- PPO updates of one run(): independent of each other, issued together ---------------------------------
@@ -769,9 +772,15 @@ class AdversarialRunner:
         if not self._concurrent_updates:
             self._flush_updates()
 
+    def _run_deferred_host(self):
+        todo, self._deferred_host = self._deferred_host, []
+        for info, st, inputs in todo:
+            info["action_complexity"] = st.get_action_complexity(inputs)
+
     def _flush_updates(self):
         jobs, self._pending_updates = self._pending_updates, []
         if not jobs:
+            self._run_deferred_host()
             return
 
         def one(agent, info, discard_grad):
@@ -781,6 +790,7 @@ class AdversarialRunner:
         if len(jobs) == 1 or self.device.type != "cuda":
             for job in jobs:
                 one(*job)
+            self._run_deferred_host()
             return
         import threading
         for agent, _, _ in jobs:                  # minibatch permutations in program order, whatever the threads do later
@@ -801,6 +811,7 @@ class AdversarialRunner:
         threads = [threading.Thread(target=work, args=(job, st)) for job, st in zip(jobs, self._update_streams)]
         for t in threads:
             t.start()
+        self._run_deferred_host()                                         # host work of this thread while the GPU trains
         for t in threads:
             t.join()
         for st in self._update_streams[:len(jobs)]:
