@@ -382,3 +382,30 @@ def test_replay_rollouts_from_per_step_graphs_equal_eager_rollouts(monkeypatch):
         assert np.array_equal(a[i], b[i], equal_nan=True)
     for k in a[5]:
         assert torch.equal(a[5][k], b[5][k]), k
+
+
+def test_rollout_return_stats_tail_from_a_suffix_of_envs():
+    """_rollout_return_stats brings only a suffix of the env axis to the host: total episode count and the last-10 returns list
+    (reference append order, adversarial_runner.py:845-853) equal the brute-force computation over the whole [T, B] buffers,
+    also when episodes are so rare that the suffix has to widen."""
+    import dcd_hip
+    runner, venv = build(make_args(ued_algo="paired", num_processes=256, num_steps=64))
+    runner.run()
+    st = runner.agents["agent"].storage
+
+    def brute():
+        info, rets = st.ep_info.t().cpu().numpy(), st.ep_ret.t().cpu().numpy()
+        b, t = np.nonzero(info & dcd_hip.INFO_EPISODE)
+        order = np.lexsort((-t, b))
+        return int(len(b)), rets[b[order], t[order]][-10:].tolist()
+    got = runner._rollout_return_stats(st)
+    assert (got["total_episodes"], got["returns_tail"]) == brute() and got["total_episodes"] >= 10
+    keep = st.ep_info.clone()
+    st.ep_info[:, 3:] &= ~dcd_hip.INFO_EPISODE                       # episodes only in the first three envs: the suffix must widen
+    got = runner._rollout_return_stats(st)
+    assert (got["total_episodes"], got["returns_tail"]) == brute()
+    st.ep_info.zero_()
+    got = runner._rollout_return_stats(st)
+    assert got["total_episodes"] == 0 and got["returns_tail"] == []
+    st.ep_info.copy_(keep)
+    venv.close()

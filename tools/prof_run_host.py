@@ -18,4 +18,4 @@ for _ in range(3): runner.run()
 torch.cuda.synchronize()
 pr = cProfile.Profile(); t = time.perf_counter(); pr.enable(); runner.run(); torch.cuda.synchronize(); pr.disable()
 print("run() s", time.perf_counter() - t)
-pstats.Stats(pr).sort_stats("cumtime").print_stats(28)
+pstats.Stats(pr).sort_stats("cumtime").print_stats(45)
