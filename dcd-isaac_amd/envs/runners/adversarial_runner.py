@@ -284,8 +284,13 @@ class AdversarialRunner:
     def _update_plr_with_current_unseen_levels(self, parent_seeds=None):
         levels = self._get_active_levels()
         self.current_level_seeds = self.level_store.insert(levels, parent_seeds=parent_seeds)
-        if self.use_byte_encoding and self.device.type == "cuda":
-            self._mirror_new_levels(self.current_level_seeds, self.ued_venv.get_encodings_device())
+        if self.device.type == "cuda":
+            if self.use_byte_encoding:
+                self._mirror_new_levels(self.current_level_seeds, self.ued_venv.get_encodings_device())
+            else:                                            # the teacher's action sequences are still in its storage: [T,B,1] -> [B,T]
+                acts = self.agents["adversary_env"].storage.actions[:, :, 0].t().contiguous()
+                self._mirror_new_levels(self.current_level_seeds, acts,
+                                        torch.full((acts.shape[0],), acts.shape[1], dtype=torch.int32, device=self.device))
         passable = self.venv.get_passable() if (self.args.log_plr_buffer_stats or self.args.reject_unsolvable_seeds) else None
         seeds, solvable = self.current_level_seeds, passable
         if self.args.reject_unsolvable_seeds:
@@ -312,36 +317,54 @@ class AdversarialRunner:
     def _sample_replay_decision(self):
         return self._default_level_sampler.sample_replay_decision()
 
-    # ---- device mirror of the level store (byte-encoded levels) --------------------------------------------------
+    # ---- device mirror of the level store ------------------------------------------------------------------------
     # A replay rollout resets envs to stored levels at every step (each finished episode, :551-558) and 4096 at its start;
-    # taking the 675-byte encodings from the host store, stacking and uploading them was 27 ms of a replay update's 140 ms
-    # of per-step host work.  The encodings of every seed in use stay in ONE device tensor; a reset sends row indices.
+    # taking the levels from the host store — 675-byte encodings stacked and uploaded, or teacher action strings split,
+    # converted and uploaded — was 27 ms of a replay update's 140 ms of per-step host work.  The levels of every seed in use
+    # stay in ONE device tensor (uint8 [rows,S,S,3] encodings, or int64 [rows,L] teacher actions + int32 lengths); a reset
+    # sends row indices.
     def _level_rows(self, seeds):
         """Rows of `seeds` in the device level table (uploading the ones it does not hold yet, in one batch)."""
         if getattr(self, "_table", None) is None:
-            S = self.venv.proto.size
-            self._table = torch.zeros((0, S, S, 3), dtype=torch.uint8, device=self.device)
+            if self.use_byte_encoding:
+                S = self.venv.proto.size
+                self._table = torch.zeros((0, S, S, 3), dtype=torch.uint8, device=self.device)
+            else:
+                self._table = torch.zeros((0, max(1, int(self.adversary_env_rollout_steps))), dtype=torch.int64, device=self.device)
+                self._table_len = torch.zeros((0,), dtype=torch.int32, device=self.device)
             self._row_of, self._free_rows = {}, []
         row_of = self._row_of
         missing = [s for s in dict.fromkeys(seeds) if s not in row_of]
         if missing:
-            enc = np.stack([np.asarray(self.level_store.get_level(s), dtype=np.uint8).reshape(self._table.shape[1:]) for s in missing])
-            self._store_rows(missing, torch.from_numpy(enc).to(self.device))
+            kind, a, b = self.venv._levels_to_device([self.level_store.get_level(s) for s in missing])
+            if (kind == "enc") != bool(self.use_byte_encoding):
+                raise RuntimeError(f"level store holds {kind!r} levels, runner expects use_byte_encoding={self.use_byte_encoding}")
+            self._store_rows(missing, a, b)
         return torch.tensor([row_of[s] for s in seeds], dtype=torch.int64, device=self.device)
 
-    def _store_rows(self, seeds, enc_dev):
-        """enc_dev [n,S,S,3] (device) are the levels of `seeds` (n distinct, not yet in the table)."""
+    def _store_rows(self, seeds, lev_dev, lens_dev=None):
+        """lev_dev (device): the levels of `seeds` (n distinct, not yet in the table) — [n,S,S,3] encodings, or [n,L] teacher
+        actions with lens_dev [n]."""
         n = len(seeds)
+        if lens_dev is not None and lev_dev.shape[1] != self._table.shape[1]:   # action tables: one width (zero padded)
+            W = max(lev_dev.shape[1], self._table.shape[1])
+            pad = lambda t: torch.cat([t, t.new_zeros((t.shape[0], W - t.shape[1]))], dim=1) if t.shape[1] < W else t
+            self._table, lev_dev = pad(self._table), pad(lev_dev)
         while len(self._free_rows) < n:                                   # grow geometrically
             old = self._table.shape[0]
             grow = max(1024, old, n)
-            self._table = torch.cat([self._table, torch.zeros((grow,) + tuple(self._table.shape[1:]), dtype=torch.uint8, device=self.device)])
+            self._table = torch.cat([self._table, self._table.new_zeros((grow,) + tuple(self._table.shape[1:]))])
+            if lens_dev is not None:
+                self._table_len = torch.cat([self._table_len, self._table_len.new_zeros((grow,))])
             self._free_rows.extend(range(old + grow - 1, old - 1, -1))
         rows = [self._free_rows.pop() for _ in range(n)]
-        self._table[torch.tensor(rows, dtype=torch.int64, device=self.device)] = enc_dev
+        rows_dev = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        self._table[rows_dev] = lev_dev
+        if lens_dev is not None:
+            self._table_len[rows_dev] = lens_dev.to(torch.int32)
         self._row_of.update(zip(seeds, rows))
 
-    def _mirror_new_levels(self, seeds, enc_dev):
+    def _mirror_new_levels(self, seeds, lev_dev, lens_dev=None):
         """After level_store.insert: the levels just built are already on the device — keep them (first row per new seed)."""
         if getattr(self, "_table", None) is None:
             self._level_rows([])
@@ -351,7 +374,7 @@ class AdversarialRunner:
                 first[s] = i
         if first:
             idx = torch.tensor(list(first.values()), dtype=torch.int64, device=self.device)
-            self._store_rows(list(first.keys()), enc_dev.index_select(0, idx))
+            self._store_rows(list(first.keys()), lev_dev.index_select(0, idx), None if lens_dev is None else lens_dev.index_select(0, idx))
 
     def _prune_level_rows(self):
         if getattr(self, "_table", None) is not None:
@@ -360,7 +383,7 @@ class AdversarialRunner:
 
     def _reset_all_to_stored_levels(self, seeds):
         """venv.reset_to_level_batch([level_store.get_level(s) for s in seeds]) (:457-465)."""
-        if self.use_byte_encoding and self.device.type == "cuda":
+        if self.device.type == "cuda":
             self._reset_to_stored_levels(list(seeds), None, self.venv.engine.student_buffers(u8=False))
             self.ued_venv.raise_errors()
         else:
@@ -368,8 +391,12 @@ class AdversarialRunner:
 
     def _reset_to_stored_levels(self, seeds, idx_dev=None, out=None):
         """reset_to_level for stored seeds (all envs, or the envs `idx_dev`) straight from the device table."""
-        enc = self._table.index_select(0, self._level_rows(seeds)) if len(seeds) else None
-        return self.venv.engine.reset_to_encoding(enc, idx_dev, out)
+        if not len(seeds):
+            return self.venv.engine.reset_to_encoding(None, idx_dev, out) if self.use_byte_encoding else None
+        rows = self._level_rows(seeds)
+        if self.use_byte_encoding:
+            return self.venv.engine.reset_to_encoding(self._table.index_select(0, rows), idx_dev, out)
+        return self.venv.engine.reset_to_actions(self._table.index_select(0, rows), self._table_len.index_select(0, rows), idx_dev, out)
 
     # ---- rollouts --------------------------------------------------------------------------------
     # Rollout steps per HIP graph.  A whole rollout is ONE graph: a fused 256-step student rollout is ~1.5k kernel nodes, a
@@ -485,12 +512,8 @@ class AdversarialRunner:
             return
         idx_dev = finished.to(torch.int32)
         u8 = st.obs_u8 is not None
-        out = self.venv.engine.student_buffers(len(idx), u8=u8, f32=not u8)
-        if self.use_byte_encoding:
-            self._reset_to_stored_levels(seeds, idx_dev, out)
-        else:
-            kind, a, b = self.venv._levels_to_device([self.level_store.get_level(s) for s in seeds])
-            self.venv.engine.reset_to_actions(a, b, idx_dev, out)
+        out = self._resample_buffers(len(idx), u8)
+        self._reset_to_stored_levels(seeds, idx_dev, out)
         if u8:
             st.obs_u8["image"][step + 1][finished] = out["image_u8"]
             st.obs_u8["direction"][step + 1][finished] = out["dir_u8"]
@@ -498,10 +521,21 @@ class AdversarialRunner:
         else:
             st._obs["image"][step + 1][finished] = out["image_f32"]
             st._obs["direction"][step + 1][finished] = out["dir_f32"]
+        cur = self.current_level_seeds                                   # this rollout's own copy (_student_rollout)
         for i, s in zip(idx, seeds):
-            self.current_level_seeds[i] = s                              # this rollout's own copy (_student_rollout)
-            rollout_info["solved_idx"][i] = True
-        self._seeds_dev[finished] = torch.tensor(seeds, dtype=torch.int32, device=self.device).view(-1, 1)
+            cur[i] = s
+        rollout_info["solved_idx"][idx] = True
+        self._seeds_dev[finished] = torch.tensor(seeds, dtype=torch.int32).to(self.device, non_blocking=True).view(-1, 1)
+
+    def _resample_buffers(self, n, u8):
+        """Observation outputs for n re-sampled envs: slices of buffers allocated once (a replay rollout asks at every step)."""
+        key = "u8" if u8 else "f32"
+        bufs = getattr(self, "_resample_out", None)
+        if bufs is None:
+            bufs = self._resample_out = {}
+        if key not in bufs:
+            bufs[key] = self.venv.engine.student_buffers(self.args.num_processes, u8=u8, f32=not u8)
+        return {k: v[:n] for k, v in bufs[key].items()}
 
     def _student_rollout(self, agent, num_steps, level_replay, level_sampler, rollout_info):
         track_seeds = level_sampler is not None

@@ -26,11 +26,15 @@ def resample(self, st, step, level_sampler, rollout_info):
     seeds = level_sampler.sample_replay_levels(len(idx)); t = tick("sample_replay_levels", t)
     T["episodes"] += len(idx)
     if not idx: return
-    rows = self._level_rows(seeds); t = tick("seed -> table rows (H2D of indices)", t)
-    enc = self._table.index_select(0, rows); t = tick("gather encodings on device", t)
     idx_dev = finished.to(torch.int32); u8 = st.obs_u8 is not None
     out = self.venv.engine.student_buffers(len(idx), u8=u8, f32=not u8); t = tick("alloc obs buffers", t)
-    self.venv.engine.reset_to_encoding(enc, idx_dev, out); t = tick("reset_to_level kernel", t)
+    if self.use_byte_encoding:
+        rows = self._level_rows(seeds); t = tick("seed -> table rows (H2D of indices)", t)
+        enc = self._table.index_select(0, rows); t = tick("gather encodings on device", t)
+        self.venv.engine.reset_to_encoding(enc, idx_dev, out); t = tick("reset_to_level kernel", t)
+    else:                                                    # levels stored as teacher action strings
+        kind, a, b = self.venv._levels_to_device([self.level_store.get_level(s) for s in seeds]); t = tick("level strings -> device", t)
+        self.venv.engine.reset_to_actions(a, b, idx_dev, out); t = tick("reset_to_actions kernel", t)
     st.obs_u8["image"][step + 1][finished] = out["image_u8"]; st.obs_u8["direction"][step + 1][finished] = out["dir_u8"]; st._stale[step + 1] = True; t = tick("scatter obs rows", t)
     for i, s in zip(idx, seeds):
         self.current_level_seeds[i] = s; rollout_info["solved_idx"][i] = True
