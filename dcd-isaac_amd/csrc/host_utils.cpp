@@ -171,6 +171,61 @@ int64_t dcd_sampler_draws(int64_t N, int64_t n, const double* w_scores, double c
   try { sw_.resize((size_t)N); w_.resize((size_t)N); cdf_.resize((size_t)N); } catch (const std::exception&) { return 0; }   // caller continues in numpy
   double* __restrict__ sw = sw_.data(); double* __restrict__ w = w_.data(); double* __restrict__ cdf = cdf_.data();
   double* __restrict__ st = staleness;
+  // ---- fast path: integer staleness counts and a 0/1 mask (what LevelSampler holds) -------------------------------------
+  // Then sw_i = staleness_i * keep_i are integers: np.sum(sw) is EXACT in any order, so z follows from two running integers
+  // (A = sum a_i keep_i, K = sum keep_i: z = A + age K) instead of a pass; and "staleness += 1" is an offset (`age`) added
+  // when an element is read, the chosen seed's base set to -(age + 1) — no pass writes the staleness array until the end.
+  // Two sweeps per draw instead of three, 4 array streams instead of 7; every value that reaches the draw is the same double.
+  bool ints = true;
+  double A = 0., K = 0.;
+  for (int64_t i = 0; i < N; ++i) {
+    const double s = st[i], kp = unseen_keep[i];
+    ints = ints && s >= 0. && s < 1e12 && s == (double)(int64_t)s && (kp == 0. || kp == 1.);
+    A += s * kp; K += kp;
+  }
+  if (ints && (double)n < 1e12) {
+    double age = 0.;
+    auto finish = [&](int64_t done) { if (age != 0.) for (int64_t i = 0; i < N; ++i) st[i] = st[i] + age; return done; };
+    for (int64_t k = 0; k < n; ++k) {
+      const double z = A + age * K;
+      if (!(z > 0)) return finish(k);
+      auto gen = [&](long i0, long m, double* __restrict__ out) {
+        for (long j = 0; j < m; ++j) {
+          const double sw1 = (st[i0 + j] + age) * unseen_keep[i0 + j];
+          const double q = sw1 / z; const double t = c * q; out[j] = w_scores[i0 + j] + t;
+        }
+      };
+      const double total = pairwise_gen(gen, w, 0, (long)N);
+      if (!(total > 1e-8 || total < -1e-8)) return finish(k);
+      double run = 0., mn = w[0];
+      const bool norm = total != 1.0;
+      constexpr int64_t BK = 32;
+      auto quot = [&](int64_t i0) {
+        const int64_t m = N - i0 < BK ? N - i0 : BK;
+        if (norm) for (int64_t j = 0; j < m; ++j) w[i0 + j] = w[i0 + j] / total;
+        double bm = mn;
+        for (int64_t j = 0; j < m; ++j) bm = w[i0 + j] < bm ? w[i0 + j] : bm;
+        mn = bm;
+      };
+      quot(0);
+      for (int64_t i0 = 0; i0 < N; i0 += BK) {
+        if (i0 + BK < N) quot(i0 + BK);
+        const int64_t m = N - i0 < BK ? N - i0 : BK;
+        for (int64_t j = 0; j < m; ++j) { run += w[i0 + j]; cdf[i0 + j] = run; }
+      }
+      const double last = cdf[N - 1];
+      if (!(last - 1.0 <= 1e-8 && 1.0 - last <= 1e-8) || mn < 0) return finish(k);
+      const double u = uniforms[k];
+      int64_t lo = 0, hi = N;
+      while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (cdf[mid] / last <= u) lo = mid + 1; else hi = mid; }
+      out_idx[k] = lo;
+      if (update_staleness) {
+        if (lo < N) { const double nb = -(age + 1.); A += (nb - st[lo]) * unseen_keep[lo]; st[lo] = nb; }
+        age += 1.;
+      }
+    }
+    return finish(n);
+  }
   bool aging = false;                                                // staleness + 1 of the previous draw still to be applied
   auto flush = [&]() { if (aging) { for (int64_t i = 0; i < N; ++i) st[i] = st[i] + 1; aging = false; } };
   for (int64_t k = 0; k < n; ++k) {

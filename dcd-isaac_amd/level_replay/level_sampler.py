@@ -454,16 +454,25 @@ class LevelSampler:
         rng_transforms = self.score_transform == "max" or (self.staleness_coef > 0 and self.staleness_transform == "max")
         if n <= 1 or rng_transforms:                                # 'max' consumes the RNG inside the transform
             return [self._sample_replay_level(update_staleness=update_staleness) for _ in range(n)]
-        unseen_keep = 1 - self.unseen_seed_weights
-        ws = self._score_transform(self.score_transform, self.temperature, self.seed_scores)
-        ws = ws * unseen_keep
-        z = np.sum(ws)
-        if z > 0:
-            ws /= z
+        # the score half of the weights depends on seed_scores / unseen_seed_weights only, which no draw changes: a replay
+        # rollout calls this once per step (256 argsorts of the buffer), so it is kept while those two arrays are unchanged
+        cached = getattr(self, "_score_half", None)
+        if (cached is not None and cached[0] == (self.score_transform, self.temperature)
+                and np.array_equal(cached[1], self.seed_scores) and np.array_equal(cached[2], self.unseen_seed_weights)):
+            unseen_keep, ws = cached[3], cached[4].copy()
         else:
-            ws = np.ones_like(ws, dtype=np.float64) / len(ws)
+            unseen_keep = 1 - self.unseen_seed_weights
+            ws = self._score_transform(self.score_transform, self.temperature, self.seed_scores)
             ws = ws * unseen_keep
-            ws /= np.sum(ws)
+            z = np.sum(ws)
+            if z > 0:
+                ws /= z
+            else:
+                ws = np.ones_like(ws, dtype=np.float64) / len(ws)
+                ws = ws * unseen_keep
+                ws /= np.sum(ws)
+            self._score_half = ((self.score_transform, self.temperature), np.array(self.seed_scores, copy=True),
+                                np.array(self.unseen_seed_weights, copy=True), unseen_keep, ws.copy())
         c, N = self.staleness_coef, len(self.seeds)
         w_scores = (1 - c) * ws if c > 0 else ws                     # constant across the batch of draws
         # 'power' with temperature 1 and eps 0 (staleness_coef > 0): (clip(s, 0) + 0) ** 1.0 is s itself, bit for bit

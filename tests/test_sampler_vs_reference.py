@@ -189,3 +189,63 @@ def test_native_draw_loop_is_numpy_bit_for_bit(monkeypatch):
         results.append((seeds, s.seed_staleness.copy(), np.random.get_state()[1].copy()))
     for seeds, stale, state in results[1:]:
         assert seeds == results[0][0] and np.array_equal(stale, results[0][1]) and np.array_equal(state, results[0][2])
+
+
+def test_native_draw_loop_paths_and_early_stops():
+    """dcd_sampler_draws has two paths — integer staleness counts with a 0/1 mask (running integer sums, lazy ageing) and the
+    general one (three passes) — both must equal the numpy statement draw for draw and leave the staleness array as numpy
+    would, also when a draw cannot be made (all staleness mass on unseen slots: the loop stops and reports how far it got) and
+    when the call is split into several calls (a replay rollout draws a few levels per step)."""
+    import ctypes as C
+    from dcd_hip import lib
+    L = lib()
+    L.dcd_sampler_draws.restype = C.c_int64
+    p_ = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def numpy_draws(wsc, c, st, keep, u):
+        st, out = st.copy(), []
+        for uj in u:
+            sw = st * keep
+            z = np.sum(sw)
+            if not z > 0:
+                break
+            w = wsc + c * (sw / z)
+            tot = np.sum(w)
+            w = w / tot if tot != 1.0 else w
+            cdf = np.cumsum(w)
+            cdf /= cdf[-1]
+            i = int(np.searchsorted(cdf, uj, side="right"))
+            out.append(i)
+            st = st + 1
+            st[i] = 0
+        return out, st
+    rng = np.random.default_rng(3)
+    for N, n, integral in ((777, 300, True), (777, 300, False), (130, 64, True), (4000, 50, True)):
+        wsc = rng.random(N)
+        wsc = 0.7 * wsc / wsc.sum()
+        keep = (rng.random(N) < 0.9).astype(np.float64)
+        st0 = rng.integers(0, 40, N).astype(np.float64) + (0.0 if integral else 0.25)
+        u = rng.random(n)
+        want, st_want = numpy_draws(wsc, 0.3, st0, keep, u)
+        st, idx = st0.copy(), np.zeros(n, dtype=np.int64)
+        k = L.dcd_sampler_draws(C.c_int64(N), C.c_int64(n), p_(wsc), C.c_double(0.3), p_(st), p_(keep), p_(u), C.c_int32(1), p_(idx))
+        assert k == n and idx.tolist() == want and np.array_equal(st, st_want), (N, integral)
+        st, got = st0.copy(), []                                     # the same draws in calls of 7
+        for j in range(0, n, 7):
+            m = min(7, n - j)
+            part, uu = np.zeros(m, dtype=np.int64), np.ascontiguousarray(u[j:j + m])
+            assert L.dcd_sampler_draws(C.c_int64(N), C.c_int64(m), p_(wsc), C.c_double(0.3), p_(st), p_(keep), p_(uu), C.c_int32(1), p_(part)) == m
+            got += part.tolist()
+        assert got == want and np.array_equal(st, st_want), (N, integral, "split")
+        st, idx = st0.copy(), np.zeros(n, dtype=np.int64)            # update_staleness = 0: the same distribution every draw
+        L.dcd_sampler_draws(C.c_int64(N), C.c_int64(5), p_(wsc), C.c_double(0.3), p_(st), p_(keep), p_(u), C.c_int32(0), p_(idx))
+        assert np.array_equal(st, st0) and idx[0] == want[0]
+    # staleness mass only where keep == 0: the first draw works (mass on seen slots), afterwards every seen slot... stops at z == 0
+    N = 50
+    keep = np.zeros(N); keep[:3] = 1.0
+    st0 = np.zeros(N); st0[:3] = 0.0; st0[3:] = 9.0
+    wsc = np.full(N, 0.7 / N)
+    u = rng.random(4)
+    st, idx = st0.copy(), np.zeros(4, dtype=np.int64)
+    k = L.dcd_sampler_draws(C.c_int64(N), C.c_int64(4), p_(wsc), C.c_double(0.3), p_(st), p_(keep), p_(u), C.c_int32(1), p_(idx))
+    assert k == 0 and np.array_equal(st, st0)                          # z = 0 at the first draw: nothing drawn, nothing aged

@@ -29,4 +29,16 @@ for j in range(min(200, n)):
     i = int(np.searchsorted(cdf, u[j], side="right")); ref.append(i)
     st = st + 1; st[i] = 0
 assert ref == idx[:len(ref)].tolist(), "mismatch vs numpy"
+st_c = st0.copy(); idx_c = np.zeros(len(ref), dtype=np.int64)
+L.dcd_sampler_draws(C.c_int64(N), C.c_int64(len(ref)), p_(wsc), C.c_double(0.3), p_(st_c), p_(keep), p_(u), C.c_int32(1), p_(idx_c))
+assert np.array_equal(st_c, st) and idx_c.tolist() == ref, "staleness after the draws differs from numpy"
+# early stop (an unseen-only buffer: z == 0) and non-integer staleness (general path) leave consistent state
+st_z = np.zeros(N); k0 = L.dcd_sampler_draws(C.c_int64(N), C.c_int64(5), p_(wsc), C.c_double(0.3), p_(st_z), p_(keep), p_(u), C.c_int32(1), p_(idx_c))
+assert k0 == 0 and not st_z.any()
+st_f = st0 + 0.5; st_n = st_f.copy(); ref_f = []
+for j in range(20):
+    sw = st_n * keep; sw = sw / np.sum(sw); w = wsc + 0.3 * sw; tot = np.sum(w); w = w / tot if tot != 1.0 else w
+    cdf = np.cumsum(w); cdf /= cdf[-1]; i = int(np.searchsorted(cdf, u[j], side="right")); ref_f.append(i); st_n = st_n + 1; st_n[i] = 0
+k1 = L.dcd_sampler_draws(C.c_int64(N), C.c_int64(20), p_(wsc), C.c_double(0.3), p_(st_f), p_(keep), p_(u), C.c_int32(1), p_(idx_c))
+assert k1 == 20 and idx_c[:20].tolist() == ref_f and np.array_equal(st_f, st_n), "general path differs from numpy"
 print("first", len(ref), "draws equal the numpy statement; checksum", int(idx.sum()), float(st0.sum()))
