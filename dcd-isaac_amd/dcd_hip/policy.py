@@ -105,7 +105,6 @@ class StudentActor:
     @staticmethod
     def input_pitch(net):
         """KP of a supported network (the GEMM operand's row pitch): known before the actor exists."""
-        conv = net.image_conv[0]
         k = net.image_embedding_size + net.scalar_embed.out_features + net.rnn.rnn.hidden_size
         return (k + 1 + 31) // 32 * 32
 
