@@ -44,3 +44,37 @@ def test_product_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(dcd_hip.DcdHipError, match="no CPU path"):
         dcd_hip.MultiGridEngine(4)
+
+
+def test_new_struct_layouts_and_argument_checks_need_no_gpu():
+    """DcdPolicyAgent / DcdStudentNet mirror the header, and the entry points added in round 2 reject bad arguments BEFORE any
+    HIP call (NULL pointers, unsupported geometry), returning non-zero with a message — callable without a device."""
+    import dcd_hip
+    from dcd_hip.policy import PolicyAgent, StudentNet
+    assert ctypes.sizeof(StudentNet) == 12 * 8 + 8 * 4
+    assert ctypes.sizeof(PolicyAgent) == 15 * 8 + 8 + 4 * 4
+    L = ctypes.CDLL(dcd_hip.LIB_PATH)
+    L.dcd_last_error.restype = ctypes.c_char_p
+    net = StudentNet()
+    for k, v in dict(V=15, F=128, E=10, D=28, H=256, A1=32, C1=32, NA=169).items():
+        setattr(net, k, v)
+    null = ctypes.c_void_p(None)
+    calls = {
+        "dcd_grid_delta_rows": lambda: L.dcd_grid_delta_rows(ctypes.byref(net), null, null, ctypes.c_int64(0), null, null, null, null, null,
+                                                             ctypes.c_int32(1), null, null, ctypes.c_int32(4), null),
+        "dcd_grid_tile_gemm": lambda: L.dcd_grid_tile_gemm(null, null, null, null, null, ctypes.c_int32(1), ctypes.c_int32(128), ctypes.c_int32(1024), null),
+        "dcd_policy_grid_rest_features": lambda: L.dcd_policy_grid_rest_features(ctypes.byref(net), null, null, ctypes.c_int32(50), null, null, null,
+                                                                                 ctypes.c_int32(320), ctypes.c_int32(4), null),
+        "dcd_policy_wide_pack_heads": lambda: L.dcd_policy_wide_pack_heads(ctypes.byref(net), null, null),
+        "dcd_policy_wide_cell_heads": lambda: L.dcd_policy_wide_cell_heads(ctypes.byref(net), null, null, null, null, null, null, null, null, null, null,
+                                                                           ctypes.c_uint32(0), ctypes.c_uint32(0), null, ctypes.c_int64(0),
+                                                                           ctypes.c_int32(0), ctypes.c_int32(4), null),
+        "dcd_policy_features_u8_pair": lambda: L.dcd_policy_features_u8_pair(null, null, ctypes.c_int32(416), ctypes.c_int32(4), null),
+        "dcd_policy_cell_heads_pair": lambda: L.dcd_policy_cell_heads_pair(null, null, ctypes.c_int32(4), null),
+    }
+    for name, call in calls.items():
+        assert call() != 0, name
+        assert L.dcd_last_error(), name
+    assert L.dcd_grid_delta_tiles(ctypes.c_int32(15), ctypes.c_int32(4096)) == (9 * 4096 + 169 * 127 + 127) // 128
+    assert L.dcd_grid_delta_tiles(ctypes.c_int32(40), ctypes.c_int32(4096)) == 0       # grid too large for the carried projection
+    assert L.dcd_policy_wide_packed_heads_floats(ctypes.byref(net)) == 0              # head weights not set -> refused
