@@ -135,13 +135,13 @@ class PairedPass:
             else:
                 eng.step(p["actions"][t], flags, outs(p, t))
                 self.twin.step(q["actions"][t], flags, outs(q, t))
-        if self.pair:                 # both students' scans in one launch each (the *_batch entry points)
+        if self.pair:                 # both students' scans: {GAE, return statistics, segment counts} in one launch, then the scoring
             ag = self.agents
-            self.scans.gae_returns_batch([(a["rewards"], a["value_preds"], a["masks"], a["returns"]) for a in ag], 0.995, 0.95)
-            self.scans.EpisodeScorer.launch_batch([a["scorer"] for a in ag],
-                                                  [(a["returns"], a["value_preds"], a["rewards"], a["masks"], a["cliff"], a["level_seeds"], None) for a in ag],
-                                                  self.dcd_hip.SCORE_STRATEGY["positive_value_loss"], 0.995)
-            self.scans.rollout_return_stats_batch([(a["ep_ret"], a["info"], a["mean_ret"], a["max_ret"], a["n_eps"]) for a in ag])
+            self.scans.rollout_tail_batch([(a["rewards"], a["value_preds"], a["masks"], a["returns"]) for a in ag],
+                                          [(a["ep_ret"], a["info"], a["mean_ret"], a["max_ret"], a["n_eps"]) for a in ag], 0.995, 0.95,
+                                          scorers=[a["scorer"] for a in ag],
+                                          score_argsets=[(a["returns"], a["value_preds"], a["rewards"], a["masks"], a["cliff"], a["level_seeds"], None) for a in ag],
+                                          strategy=self.dcd_hip.SCORE_STRATEGY["positive_value_loss"])
         else:
             for a in self.agents:
                 self.scans.gae_returns(a["rewards"], a["value_preds"], a["masks"], a["returns"], 0.995, 0.95)

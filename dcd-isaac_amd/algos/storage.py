@@ -320,17 +320,23 @@ class RolloutStorage:
         scans.discounted_returns(self.rewards, self._value_source(next_value), self.masks, returns_buffer, gamma)
 
     @staticmethod
-    def compute_returns_batch(storages, next_values, use_gae, gamma, gae_lambda):
-        """compute_returns of several storages of one shape (PAIRED: protagonist and antagonist) with ONE scan launch."""
+    def compute_returns_batch(storages, next_values, use_gae, gamma, gae_lambda, stat_sets=None):
+        """compute_returns of several storages of one shape (PAIRED: protagonist and antagonist) with ONE scan launch;
+        stat_sets (rollout_return_stats_batch's argument): the rollouts' return statistics ride in the same launch."""
         if not use_gae or len(storages) == 1 or len({(s.num_steps, s.num_processes) for s in storages}) != 1:
             for s, nv in zip(storages, next_values):
                 s.compute_returns(nv, use_gae, gamma, gae_lambda)
+            if stat_sets is not None:
+                scans.rollout_return_stats_batch(stat_sets)
             return
         sets = []
         for s, nv in zip(storages, next_values):
             v = s._value_source(nv)
             sets.append((s.rewards, s.denorm_value_preds if s.use_popart else v, s.masks, s.returns))
-        scans.gae_returns_batch(sets, gamma, gae_lambda)
+        if stat_sets is not None:
+            scans.rollout_tail_batch(sets, stat_sets, gamma, gae_lambda)
+        else:
+            scans.gae_returns_batch(sets, gamma, gae_lambda)
 
     def compute_returns(self, next_value, use_gae, gamma, gae_lambda):
         if use_gae:

@@ -27,10 +27,9 @@ constexpr int UNROLL = 32;   // time steps whose loads are in flight ahead of th
 struct GaeSets { const float* rew[DCD_MAX_SCAN_SETS]; const float* val[DCD_MAX_SCAN_SETS]; const float* msk[DCD_MAX_SCAN_SETS]; float* ret[DCD_MAX_SCAN_SETS]; };
 
 // compute_gae_returns (algos/storage.py:249-256)
-__global__ void __launch_bounds__(SCAN_BLOCK) gae_kernel(GaeSets sets, int T, int B, float g, float gl) {
-  const float* __restrict__ rew = sets.rew[blockIdx.y]; const float* __restrict__ val = sets.val[blockIdx.y];
-  const float* __restrict__ msk = sets.msk[blockIdx.y]; float* __restrict__ ret = sets.ret[blockIdx.y];
-  const int b = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+__device__ __forceinline__ void gae_body(const GaeSets& sets, int set, int b, int T, int B, float g, float gl) {
+  const float* __restrict__ rew = sets.rew[set]; const float* __restrict__ val = sets.val[set];
+  const float* __restrict__ msk = sets.msk[set]; float* __restrict__ ret = sets.ret[set];
   if (b >= B) return;
   float gae = 0.0f;
   float v1 = val[(size_t)T * B + b];
@@ -59,6 +58,9 @@ __global__ void __launch_bounds__(SCAN_BLOCK) gae_kernel(GaeSets sets, int T, in
     ret[(size_t)t * B + b] = gae + v0;
     v1 = v0;
   }
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) gae_kernel(GaeSets sets, int T, int B, float g, float gl) {
+  gae_body(sets, blockIdx.y, blockIdx.x * SCAN_BLOCK + threadIdx.x, T, B, g, gl);
 }
 
 // compute_discounted_returns (algos/storage.py:271-276)
@@ -298,12 +300,12 @@ constexpr int SWEEPS = STILE / (SNT / (SE / 4));   // rows a thread loads per ar
 // counts[b] = 1 + #{t in [1, T) : masks[t][b] == 0}; block_sums[b / 32] = sum of counts over the 32-env block.
 // Workgroup = 64 envs x 4 time quarters (one wave each), every wave's loads in flight together.
 struct CountSets { const float* msk[DCD_MAX_SCAN_SETS]; int* counts[DCD_MAX_SCAN_SETS]; int* block_sums[DCD_MAX_SCAN_SETS]; };
-__global__ void __launch_bounds__(256) seg_count_par_kernel(CountSets sets, int T, int B) {
-  const float* __restrict__ msk = sets.msk[blockIdx.y]; int* __restrict__ counts = sets.counts[blockIdx.y];
-  int* __restrict__ block_sums = sets.block_sums[blockIdx.y];
+__device__ __forceinline__ void seg_count_par_body(const CountSets& sets, int set, int bx, int T, int B) {
+  const float* __restrict__ msk = sets.msk[set]; int* __restrict__ counts = sets.counts[set];
+  int* __restrict__ block_sums = sets.block_sums[set];
   __shared__ int part[4][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int b = blockIdx.x * 64 + lane;
+  const int b = bx * 64 + lane;
   const int per = (T - 1 + 3) / 4, t_lo = 1 + q * per, t_hi = min(t_lo + per, T);
   int n = 0;
   if (b < B) {
@@ -324,8 +326,11 @@ __global__ void __launch_bounds__(256) seg_count_par_kernel(CountSets sets, int 
     int sum = n;
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);                 // within each half-wave of 32
-    if ((lane & 31) == 0 && blockIdx.x * 64 + lane < B) block_sums[(blockIdx.x * 64 + lane) >> 5] = sum;
+    if ((lane & 31) == 0 && bx * 64 + lane < B) block_sums[(bx * 64 + lane) >> 5] = sum;
   }
+}
+__global__ void __launch_bounds__(256) seg_count_par_kernel(CountSets sets, int T, int B) {
+  seg_count_par_body(sets, blockIdx.y, blockIdx.x, T, B);
 }
 
 // The staged kernel's sequential lanes only PARK a finished segment in its record slot (sums as accumulated, no
@@ -502,11 +507,10 @@ __global__ void __launch_bounds__(SCAN_BLOCK) grounded_kernel(const DcdEpisodeRe
 
 // _get_rollout_return_stats (envs/runners/adversarial_runner.py:257-271)
 struct StatSets { const float* ep_ret[DCD_MAX_SCAN_SETS]; const uint8_t* info[DCD_MAX_SCAN_SETS]; float* mean_r[DCD_MAX_SCAN_SETS]; float* max_r[DCD_MAX_SCAN_SETS]; int* n_eps[DCD_MAX_SCAN_SETS]; };
-__global__ void __launch_bounds__(SCAN_BLOCK) return_stats_kernel(StatSets sets, int T, int B) {
-  const float* __restrict__ ep_ret = sets.ep_ret[blockIdx.y]; const uint8_t* __restrict__ info = sets.info[blockIdx.y];
-  float* __restrict__ mean_r = sets.mean_r[blockIdx.y]; float* __restrict__ max_r = sets.max_r[blockIdx.y];
-  int* __restrict__ n_eps = sets.n_eps[blockIdx.y];
-  const int b = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+__device__ __forceinline__ void return_stats_body(const StatSets& sets, int set, int b, int T, int B) {
+  const float* __restrict__ ep_ret = sets.ep_ret[set]; const uint8_t* __restrict__ info = sets.info[set];
+  float* __restrict__ mean_r = sets.mean_r[set]; float* __restrict__ max_r = sets.max_r[set];
+  int* __restrict__ n_eps = sets.n_eps[set];
   if (b >= B) return;
   double acc = 0.0; float mx = -INFINITY; int n = 0;
   for (int t0 = 0; t0 < T; t0 += UNROLL) {
@@ -520,6 +524,20 @@ __global__ void __launch_bounds__(SCAN_BLOCK) return_stats_kernel(StatSets sets,
   mean_r[b] = n ? (float)(acc / (double)n) : 0.f;
   max_r[b] = n ? mx : 0.f;
   if (n_eps) n_eps[b] = n;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) return_stats_kernel(StatSets sets, int T, int B) {
+  return_stats_body(sets, blockIdx.y, blockIdx.x * SCAN_BLOCK + threadIdx.x, T, B);
+}
+
+// The scans that follow a pair of rollouts and do not depend on each other — GAE, return statistics, segment counts, each for
+// up to two rollouts — side by side in ONE launch: blockIdx.y = kind * n + set.  Each is latency-bound on 64 ... 256 waves, so
+// the launch takes the time of the longest (GAE) instead of their sum.  256-thread workgroups: GAE / statistics take one env
+// per thread (the first ceil(B / 256) workgroups of their rows), the count 64 envs x 4 time quarters per workgroup.
+__global__ void __launch_bounds__(256) rollout_tail_kernel(GaeSets gs, StatSets ss, CountSets cs, int n, int n_count, int T, int B, float g, float gl) {
+  const int y = blockIdx.y;
+  if (y < n) { if (blockIdx.x * 256 < B) gae_body(gs, y, blockIdx.x * 256 + threadIdx.x, T, B, g, gl); }
+  else if (y < 2 * n) { if (blockIdx.x * 256 < B) return_stats_body(ss, y - n, blockIdx.x * 256 + threadIdx.x, T, B); }
+  else if (y - 2 * n < n_count) { if (blockIdx.x * 64 < B) seg_count_par_body(cs, y - 2 * n, blockIdx.x, T, B); }
 }
 
 // _compute_env_return (envs/runners/adversarial_runner.py:637-664)
@@ -628,19 +646,28 @@ static int check_score_set(const DcdEpisodeScoreArgs& q, int32_t T, int32_t B, i
   return 0;
 }
 
-int dcd_episode_scores_batch(int32_t n, const DcdEpisodeScoreArgs* q, int32_t T, int32_t B, int32_t A, int32_t strategy, double gamma,
-                             void* stream) {
+// the LDS-staged scoring path (time-parallel counts + tile kernel) applies: value / TD / uniform strategies, B % 32 == 0, aligned
+static bool scores_staged(int32_t n, const DcdEpisodeScoreArgs* q, int32_t B, int32_t strategy) {
+  const bool needs_logits = strategy == DCD_SCORE_POLICY_ENTROPY || strategy == DCD_SCORE_LEAST_CONFIDENCE || strategy == DCD_SCORE_MIN_MARGIN;
+  const bool needs_returns = strategy <= DCD_SCORE_SIGNED_VALUE_LOSS;
+  auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  bool staged = !needs_logits && B % SE == 0 && B <= (1 << 18);
+  for (int k = 0; k < n && staged; ++k)
+    staged = aligned16(q[k].rewards) && aligned16(q[k].masks) && aligned16(q[k].cliffhanger_masks) && aligned16(q[k].level_seeds) &&
+             aligned16(q[k].value_preds) && (!needs_returns || aligned16(q[k].returns));
+  return staged;
+}
+
+static int episode_scores_impl(int32_t n, const DcdEpisodeScoreArgs* q, int32_t T, int32_t B, int32_t A, int32_t strategy, double gamma,
+                               void* stream, bool counts_done) {
   if (n < 1 || n > DCD_MAX_SCAN_SETS || !q) return dcd::fail("dcd_episode_scores_batch: 1 <= n <= %d sets", DCD_MAX_SCAN_SETS);
   if (strategy < 0 || strategy > DCD_SCORE_RETURN_SUM) return dcd::fail("dcd_episode_scores: unknown strategy %d", strategy);
   const bool needs_logits = strategy == DCD_SCORE_POLICY_ENTROPY || strategy == DCD_SCORE_LEAST_CONFIDENCE || strategy == DCD_SCORE_MIN_MARGIN;
   const bool needs_returns = strategy <= DCD_SCORE_SIGNED_VALUE_LOSS;
   for (int k = 0; k < n; ++k) if (check_score_set(q[k], T, B, A, strategy, needs_logits, needs_returns)) return 1;
   hipStream_t s = (hipStream_t)stream;
-  auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-  bool staged = !needs_logits && B % SE == 0 && B <= (1 << 18);
-  for (int k = 0; k < n && staged; ++k)
-    staged = aligned16(q[k].rewards) && aligned16(q[k].masks) && aligned16(q[k].cliffhanger_masks) && aligned16(q[k].level_seeds) &&
-             aligned16(q[k].value_preds) && (!needs_returns || aligned16(q[k].returns));
+  const bool staged = scores_staged(n, q, B, strategy);
+  if (counts_done && !staged) return dcd::fail("dcd_episode_scores: internal: counts_done on the unstaged path");
   auto fill = [&](ScoreArgs& a, const DcdEpisodeScoreArgs& x) {
     a.ret = x.returns; a.val = x.value_preds; a.rew = x.rewards; a.msk = x.masks; a.cliff = x.cliffhanger_masks; a.logits = x.action_log_dist;
     a.seeds = x.level_seeds; a.T = T; a.B = B; a.A = A; a.strategy = strategy; a.g = (float)gamma; a.recs = x.recs; a.max_recs = x.max_recs;
@@ -656,7 +683,7 @@ int dcd_episode_scores_batch(int32_t n, const DcdEpisodeScoreArgs* q, int32_t T,
       sets.counts[k] = counts; sets.block_sums[k] = block_sums; sets.n_recs[k] = q[k].n_recs;
       cs.msk[k] = q[k].masks; cs.counts[k] = counts; cs.block_sums[k] = block_sums;
     }
-    hipLaunchKernelGGL(seg_count_par_kernel, dim3((B + 63) / 64, n), dim3(256), 0, s, cs, T, B);
+    if (!counts_done) hipLaunchKernelGGL(seg_count_par_kernel, dim3((B + 63) / 64, n), dim3(256), 0, s, cs, T, B);
     switch (strategy) {
 #define DCD_SCORE_CASE(ST) case ST: hipLaunchKernelGGL(seg_score_lds_kernel<ST>, dim3(B / SE, n), dim3(SNT), 0, s, sets); break;
       DCD_SCORE_CASE(0) DCD_SCORE_CASE(1) DCD_SCORE_CASE(2) DCD_SCORE_CASE(6) DCD_SCORE_CASE(7) DCD_SCORE_CASE(8)
@@ -678,6 +705,46 @@ int dcd_episode_scores_batch(int32_t n, const DcdEpisodeScoreArgs* q, int32_t T,
     }
   }
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int dcd_episode_scores_batch(int32_t n, const DcdEpisodeScoreArgs* q, int32_t T, int32_t B, int32_t A, int32_t strategy, double gamma,
+                             void* stream) {
+  return episode_scores_impl(n, q, T, B, A, strategy, gamma, stream, false);
+}
+
+int dcd_rollout_tail_batch(int32_t n, const float* const* rewards, const float* const* value_preds, const float* const* masks,
+                           float* const* returns, const float* const* ep_ret, const uint8_t* const* info, float* const* mean_return,
+                           float* const* max_return, int32_t* const* n_episodes, const DcdEpisodeScoreArgs* score, int32_t T, int32_t B,
+                           int32_t A, int32_t strategy, double gamma, double gae_lambda, void* stream) {
+  if (n < 1 || n > DCD_MAX_SCAN_SETS || !rewards || !value_preds || !masks || !returns || !ep_ret || !info || !mean_return || !max_return ||
+      T <= 0 || B <= 0)
+    return dcd::fail("dcd_rollout_tail_batch: bad arguments (1 <= n <= %d)", DCD_MAX_SCAN_SETS);
+  GaeSets gs; memset(&gs, 0, sizeof gs);
+  StatSets ss; memset(&ss, 0, sizeof ss);
+  CountSets cs; memset(&cs, 0, sizeof cs);
+  for (int k = 0; k < n; ++k) {
+    if (!rewards[k] || !value_preds[k] || !masks[k] || !returns[k] || !ep_ret[k] || !info[k] || !mean_return[k] || !max_return[k])
+      return dcd::fail("dcd_rollout_tail_batch: null pointer in set %d", k);
+    gs.rew[k] = rewards[k]; gs.val[k] = value_preds[k]; gs.msk[k] = masks[k]; gs.ret[k] = returns[k];
+    ss.ep_ret[k] = ep_ret[k]; ss.info[k] = info[k]; ss.mean_r[k] = mean_return[k]; ss.max_r[k] = max_return[k];
+    ss.n_eps[k] = n_episodes ? n_episodes[k] : nullptr;
+  }
+  int n_count = 0;                                                   // counts ride along when the scoring takes the staged path
+  if (score) {
+    if (strategy < 0 || strategy > DCD_SCORE_RETURN_SUM) return dcd::fail("dcd_rollout_tail_batch: unknown strategy %d", strategy);
+    const bool needs_logits = strategy == DCD_SCORE_POLICY_ENTROPY || strategy == DCD_SCORE_LEAST_CONFIDENCE || strategy == DCD_SCORE_MIN_MARGIN;
+    for (int k = 0; k < n; ++k) if (check_score_set(score[k], T, B, A, strategy, needs_logits, strategy <= DCD_SCORE_SIGNED_VALUE_LOSS)) return 1;
+    if (scores_staged(n, score, B, strategy)) {
+      n_count = n;
+      for (int k = 0; k < n; ++k) { cs.msk[k] = score[k].masks; cs.counts[k] = score[k].workspace; cs.block_sums[k] = score[k].workspace + B; }
+    }
+  }
+  const unsigned gx = (unsigned)((B + 63) / 64);                     // >= ceil(B / 256): the GAE / statistics rows use a prefix of it
+  hipLaunchKernelGGL(rollout_tail_kernel, dim3(n_count ? gx : (unsigned)((B + 255) / 256), 2 * n + n_count), dim3(256), 0, (hipStream_t)stream,
+                     gs, ss, cs, n, n_count, T, B, (float)gamma, (float)(gamma * gae_lambda));
+  HIP_OK(hipGetLastError());
+  if (score) return episode_scores_impl(n, score, T, B, A, strategy, gamma, stream, n_count > 0);
   return 0;
 }
 

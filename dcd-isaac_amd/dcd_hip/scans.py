@@ -118,6 +118,24 @@ class EpisodeScorer:
         check(lib().dcd_episode_scores_batch(C.c_int32(len(scorers)), arr, C.c_int32(T), C.c_int32(B), C.c_int32(A), C.c_int32(strategy),
                                              C.c_double(gamma), stream_ptr()))
 
+    @staticmethod
+    def _arg_array(scorers, argsets):
+        T, B = scorers[0].T, scorers[0].B
+        arr = (ScoreArgs * len(scorers))()
+        A = 0
+        for k, (sc, a) in enumerate(zip(scorers, argsets)):
+            ld = None
+            if a[6] is not None:
+                A = a[6].shape[-1]
+                ld = ptr(a[6], torch.float32, T * B * A, "action_log_dist")
+            vals = [_tb(a[0], T + 1, B, "returns"), _tb(a[1], T + 1, B, "value_preds"), _tb(a[2], T, B, "rewards"),
+                    _tb(a[3], T + 1, B, "masks"), _tb(a[4], T + 1, B, "cliffhanger_masks"), _tb(a[5], T, B, "level_seeds", torch.int32), ld,
+                    ptr(sc.recs)]
+            for name, v in zip(("returns", "value_preds", "rewards", "masks", "cliffhanger_masks", "level_seeds", "action_log_dist", "recs"), vals):
+                setattr(arr[k], name, v.value if v is not None else None)
+            arr[k].max_recs, arr[k].n_recs, arr[k].workspace = sc.max_recs, ptr(sc.n_recs).value, ptr(sc.workspace).value
+        return arr, A
+
     def records(self):
         """Synchronises: returns the records as a numpy structured array (reference order)."""
         n = int(self.n_recs.item())
@@ -165,3 +183,22 @@ def env_return(agent_mean, agent_max, adv_mean, adv_max, mode=0, out=None):
                                ptr(adv_mean, torch.float32, B), ptr(adv_max, torch.float32, B),
                                ptr(out, torch.float32, B), C.c_int32(B), C.c_int32(mode), stream_ptr()))
     return out
+
+
+def rollout_tail_batch(gae_sets, stat_sets, gamma, gae_lambda, scorers=None, score_argsets=None, strategy=0):
+    """dcd_rollout_tail_batch: what follows a pair of rollouts in two launches (one without scoring) —
+    gae_sets = [(rewards, value_preds, masks, returns), ...] as `gae_returns_batch`, stat_sets = [(ep_ret, info, mean_out, max_out,
+    n_out), ...] as `rollout_return_stats_batch`, and optionally the scorers / argument sets of `EpisodeScorer.launch_batch`."""
+    T, B = gae_sets[0][0].shape[0], gae_sets[0][0].shape[1]
+    n = len(gae_sets)
+    g = [[_tb(st[0], T, B, "rewards") for st in gae_sets], [_tb(st[1], T + 1, B, "value_preds") for st in gae_sets],
+         [_tb(st[2], T + 1, B, "masks") for st in gae_sets], [_tb(st[3], T + 1, B, "returns") for st in gae_sets]]
+    q = [[ptr(st[0], torch.float32, T * B, "ep_ret") for st in stat_sets], [ptr(st[1], torch.uint8, T * B, "info") for st in stat_sets],
+         [ptr(st[2], torch.float32, B) for st in stat_sets], [ptr(st[3], torch.float32, B) for st in stat_sets],
+         [ptr(st[4], torch.int32, B) for st in stat_sets]]
+    ga, qa = [_ptr_array(c) for c in g], [_ptr_array(c) for c in q]
+    arr, A = (None, 0)
+    if scorers is not None:
+        arr, A = EpisodeScorer._arg_array(scorers, score_argsets)
+    check(lib().dcd_rollout_tail_batch(C.c_int32(n), ga[0], ga[1], ga[2], ga[3], qa[0], qa[1], qa[2], qa[3], qa[4], arr, C.c_int32(T), C.c_int32(B),
+                                       C.c_int32(A), C.c_int32(strategy), C.c_double(gamma), C.c_double(gae_lambda), stream_ptr()))

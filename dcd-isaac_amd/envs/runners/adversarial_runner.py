@@ -684,14 +684,16 @@ class AdversarialRunner:
         B = self.args.num_processes
         outs = [(torch.empty((B, 1), device=self.device), torch.empty((B, 1), device=self.device),
                  torch.empty((B,), dtype=torch.int32, device=self.device)) for _ in agents]
-        scans.rollout_return_stats_batch([(a.storage.ep_ret, a.storage.ep_info) + o for a, o in zip(agents, outs)])
+        stat_sets = [(a.storage.ep_ret, a.storage.ep_info) + o for a, o in zip(agents, outs)]
         self._pair_cache = {id(a): {"stats": o} for a, o in zip(agents, outs)}
         if self.is_training:
             nvs = [self._bootstrap_value(a) for a in agents]
             type(agents[0].storage).compute_returns_batch([a.storage for a in agents], nvs, self.args.use_gae, self.args.gamma,
-                                                          self.args.gae_lambda)
+                                                          self.args.gae_lambda, stat_sets=stat_sets)
             for a in agents:
                 self._pair_cache[id(a)]["returns"] = True
+        else:
+            scans.rollout_return_stats_batch(stat_sets)
 
     def _paired_rollout_body(self, agents, num_steps, t0, t1, track_seeds):
         args, venv = self.args, self.venv

@@ -329,6 +329,16 @@ int dcd_rollout_return_stats(const float* ep_ret, const uint8_t* info, int32_t T
 int dcd_rollout_return_stats_batch(int32_t n, const float* const* ep_ret, const uint8_t* const* info, int32_t T, int32_t B,
                                    float* const* mean_return, float* const* max_return, int32_t* const* n_episodes,
                                    void* stream);
+/* Everything that follows a pair of rollouts, in TWO launches instead of four: GAE (dcd_gae_returns_batch), return statistics
+ * (dcd_rollout_return_stats_batch) and — when `score` is given and its strategy takes the staged path — the episode segment
+ * counts of dcd_episode_scores_batch side by side in one launch (they do not depend on each other and each is
+ * latency-bound), then the episode scoring, which reads the returns just written.  score may be NULL (no level replay):
+ * one launch.  Results are those of the three separate calls, bit for bit. */
+int dcd_rollout_tail_batch(int32_t n, const float* const* rewards, const float* const* value_preds, const float* const* masks,
+                           float* const* returns, const float* const* ep_ret, const uint8_t* const* info,
+                           float* const* mean_return, float* const* max_return, int32_t* const* n_episodes,
+                           const DcdEpisodeScoreArgs* score, int32_t T, int32_t B, int32_t A, int32_t strategy, double gamma,
+                           double gae_lambda, void* stream);
 /* _compute_env_return (adversarial_runner.py:637-674), mode 0 paired
  * max(antag_max - protag_mean, 0); 1 flexible_paired; 2 minimax (-protag_max). */
 int dcd_env_return(const float* agent_mean, const float* agent_max, const float* adv_mean,

@@ -252,3 +252,48 @@ def test_batched_scans_equal_the_single_launches():
             assert len(a) == len(b) > 0 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
             for x, y in zip(outs[k], single[k][2]):
                 assert torch.equal(x.view(-1), y.view(-1))
+
+
+@pytest.mark.parametrize("T,B,with_scores", [(256, 4096, True), (64, 96, True), (33, 100, True), (64, 256, False)])
+def test_rollout_tail_batch_equals_the_separate_calls(T, B, with_scores):
+    """dcd_rollout_tail_batch ({GAE, return statistics, segment counts} of two rollouts side by side in one launch, then the
+    scoring) == gae_returns_batch + rollout_return_stats_batch + EpisodeScorer.launch_batch, bit for bit — returns, statistics,
+    records and record counts; B = 100 is not a multiple of 32: the scoring falls back to the one-env-per-lane path and the
+    counts are not fused; with_scores = False: the single-launch form without level replay."""
+    from dcd_hip import SCORE_STRATEGY, scans
+    g = torch.Generator().manual_seed(T * 7 + B)
+    def rollout():
+        r = dict(rewards=(torch.rand(T, B, generator=g) * (torch.rand(T, B, generator=g) < 0.05)).to(DEV),
+                 value_preds=torch.randn(T + 1, B, generator=g).to(DEV),
+                 masks=(torch.rand(T + 1, B, generator=g) > 0.03).float().to(DEV), cliff=(torch.rand(T + 1, B, generator=g) > 0.01).float().to(DEV),
+                 seeds=torch.randint(0, 1000, (T, B), generator=g).to(torch.int32).to(DEV),
+                 ep_ret=torch.rand(T, B, generator=g).to(DEV), info=((torch.rand(T, B, generator=g) < 0.03) * 1).to(torch.uint8).to(DEV))
+        r["masks"][0] = 1.0
+        return r
+    rolls = [rollout(), rollout()]
+    def run(fused):
+        outs = []
+        for r in rolls:
+            outs.append(dict(returns=torch.zeros(T + 1, B, device=DEV), mean=torch.zeros(B, 1, device=DEV), mx=torch.zeros(B, 1, device=DEV),
+                             n=torch.zeros(B, dtype=torch.int32, device=DEV), scorer=scans.EpisodeScorer(T, B, DEV)))
+        gae = [(r["rewards"], r["value_preds"], r["masks"], o["returns"]) for r, o in zip(rolls, outs)]
+        st = [(r["ep_ret"], r["info"], o["mean"], o["mx"], o["n"]) for r, o in zip(rolls, outs)]
+        sa = [(o["returns"], r["value_preds"], r["rewards"], r["masks"], r["cliff"], r["seeds"], None) for r, o in zip(rolls, outs)]
+        sc = [o["scorer"] for o in outs]
+        strat = SCORE_STRATEGY["positive_value_loss"]
+        if fused:
+            scans.rollout_tail_batch(gae, st, 0.995, 0.95, scorers=sc if with_scores else None, score_argsets=sa if with_scores else None, strategy=strat)
+        else:
+            scans.gae_returns_batch(gae, 0.995, 0.95)
+            scans.rollout_return_stats_batch(st)
+            if with_scores:
+                scans.EpisodeScorer.launch_batch(sc, sa, strat, 0.995)
+        torch.cuda.synchronize()
+        return outs
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        for k in ("returns", "mean", "mx", "n"):
+            assert torch.equal(x[k], y[k]), k
+        if with_scores:
+            rx, ry = x["scorer"].records(), y["scorer"].records()
+            assert len(rx) == len(ry) > 0 and rx.tobytes() == ry.tobytes()
