@@ -126,14 +126,10 @@ class PairedPass:
                                                "random_z": adv["random_z"][k + 1], "done": adv["done"][k]})
         # protagonist and antagonist play the teacher's levels in independent rollouts (adversarial_runner.py:709-733):
         # each on its own copy of the env records, both advanced by ONE launch per step
+        self.twin.clone_levels(eng)
         engines = (eng, self.twin)
-        if self.pair:                                   # copy + both reset_agent calls in one launch (dcd_mg_reset_agent_pair)
-            eng.reset_agent_pair(self.twin, *[{self.img_key: a["image"][0], self.dir_key: a["direction"][0]} for a in self.agents])
-        else:
-            self.twin.clone_levels(eng)
         for ai, a in enumerate(self.agents):
-            if not self.pair:
-                engines[ai].reset_agent({self.img_key: a["image"][0], self.dir_key: a["direction"][0]})
+            engines[ai].reset_agent({self.img_key: a["image"][0], self.dir_key: a["direction"][0]})
         outs = self.step_outs
         p, q = self.agents
         for t in range(T):

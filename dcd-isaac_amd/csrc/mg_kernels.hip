@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
 
 // =================================================================================== level ops
 enum LevelOp { OP_RESET = 0, OP_STEP_ADV, OP_RESET_AGENT, OP_RESET_RANDOM, OP_SET_ENCODING, OP_REPLAY, OP_MUTATE,
-               OP_READ_ENC, OP_FIXED_LEVEL, OP_RESET_AGENT_PAIR };
+               OP_READ_ENC, OP_FIXED_LEVEL };
 
 struct LevelArgs {
   uint8_t* rec; const uint32_t* seed; Metrics* met; uint32_t* errs;
@@ -401,8 +401,6 @@ struct LevelArgs {
   DcdAdvObs adv; uint8_t* adv_done;               // teacher outputs
   DcdStudentObs stu;                              // student outputs
   uint8_t* enc_out;                               // OP_READ_ENC [B,S,S,3]
-  // OP_RESET_AGENT_PAIR: the second replica (records, keys, metrics) receives a copy of the reset envs, stu2 their observation
-  uint8_t* rec2; uint32_t* seed2; Metrics* met2; DcdStudentObs stu2;
 };
 
 // full-grid observation of the workgroup's n envs: u8 [x][y][c] and/or fp32 CHW /10, contiguous per
@@ -479,11 +477,10 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
       e.ep_ret = 0.f; e.ep_len = 0;                 // VecMonitor.reset (vec_monitor.py:36-40)
     } else if (OP == OP_STEP_ADV) {
       done = env_step_adversary(e, p, m, a.loc[env], nullptr);
-    } else if (OP == OP_RESET_AGENT || OP == OP_RESET_AGENT_PAIR) {
+    } else if (OP == OP_RESET_AGENT) {
       reset_agent(e);
       e.elapsed = 0;                                // time_limit.py:47-49
       e.ep_ret = 0.f; e.ep_len = 0;                 // vec_monitor.py:42-46
-      if (OP == OP_RESET_AGENT_PAIR) { a.seed2[env] = a.seed[env]; a.met2[env] = m; }
     } else if (OP == OP_RESET_RANDOM) {
       env_reset_random(e, p, m);
       e.elapsed = 0;                                // time_limit.py:39-41
@@ -521,7 +518,6 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
   }
   __syncthreads();
   if (OP != OP_READ_ENC) stage_out<NT>(lds, a.rec, [&](int r) { return env_of[r]; }, n, tid);
-  if (OP == OP_RESET_AGENT_PAIR) stage_out<NT>(lds, a.rec2, [&](int r) { return env_of[r]; }, n, tid);
   if (ADV_OUT) {
     if (OP != OP_READ_ENC && a.adv.random_z) {
       // generate_random_z (adversarial.py:449-450): (row, q) pairs, one Philox block = 4 floats each
@@ -542,7 +538,6 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
     else emit_grid<0, NT>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
   } else {
     render_emit_v<EPB, NT>(lds, lut, a.stu, (size_t)row0, n, p, tid);
-    if (OP == OP_RESET_AGENT_PAIR) render_emit_v<EPB, NT>(lds, lut, a.stu2, (size_t)row0, n, p, tid);
   }
 }
 
@@ -794,18 +789,6 @@ int dcd_mg_clone_levels(DcdMg* dst, DcdMg* src, void* stream) {
                      reinterpret_cast<const uint4*>(src->met), reinterpret_cast<uint4*>(dst->met));
   HIP_OK(hipGetLastError());
   return 0;
-}
-
-int dcd_mg_reset_agent_pair(DcdMg* h0, DcdMg* h1, const DcdStudentObs* out0, const DcdStudentObs* out1, void* stream) {
-  CHECK_H(h0); CHECK_H(h1);
-  NO_BIG(h0, "dcd_mg_reset_agent_pair"); NO_BIG(h1, "dcd_mg_reset_agent_pair");
-  if (h0->p.B != h1->p.B || h0->p.S != h1->p.S || h0->device != h1->device || h0->rec == h1->rec)
-    return dcd::fail("dcd_mg_reset_agent_pair: the handles must be two replicas of one batch");
-  LevelArgs a = base_args(h0);
-  a.rec2 = h1->rec; a.seed2 = h1->seed; a.met2 = h1->met;
-  if (out0) a.stu = *out0;
-  if (out1) a.stu2 = *out1;
-  return launch_level<OP_RESET_AGENT_PAIR>(h0, a, stream);
 }
 
 int dcd_mg_set_seed(DcdMg* h, const int64_t* seeds, void* stream) {

@@ -58,11 +58,6 @@ class MultiGridEngine:
         """self := src (grids, agent / episode state, Philox keys and counters, metrics)."""
         check(lib().dcd_mg_clone_levels(self._h, src._h, stream_ptr()))
 
-    def reset_agent_pair(self, other, out, other_out):
-        """other.clone_levels(self); self.reset_agent(out); other.reset_agent(other_out) in ONE launch (dcd_mg_reset_agent_pair)."""
-        st0, st1 = self._student_struct(out, self.B), self._student_struct(other_out, self.B)
-        check(lib().dcd_mg_reset_agent_pair(self._h, other._h, C.byref(st0), C.byref(st1), stream_ptr()))
-
     def step_pair(self, other, actions, other_actions, flags=0, out=None, other_out=None):
         """dcd_mg_step of this replica and the next one (`other`) in ONE launch."""
         st0, st1 = self._step_struct(out), self._step_struct(other_out)

@@ -698,8 +698,10 @@ class AdversarialRunner:
     def _paired_rollout_body(self, agents, num_steps, t0, t1, track_seeds):
         args, venv = self.args, self.venv
         sts = [a.storage for a in agents]
-        if t0 == 0:                                        # copy the levels to the second replica, reset_agent on both (:484): one launch
-            venv.reset_agent_pair_device(sts[0].student_obs_out(0), sts[1].student_obs_out(0))
+        if t0 == 0:
+            venv.clone_to_twin()
+            venv.reset_agent_device(sts[0].student_obs_out(0))
+            venv.reset_agent_twin_device(sts[1].student_obs_out(0))
         fused = [self._fused_actor(a) if self.is_discrete_actions else None for a in agents]
         pa = getattr(self, "_pair_actors", None)
         both = (pa is not None and all(f is not None for f in fused) and all(f is g for f, g in zip(fused, pa.actors))

@@ -144,11 +144,6 @@ class HipAdversarialVecEnv:
     def reset_agent_twin_device(self, out):
         return self.twin.reset_agent(out)
 
-    def reset_agent_pair_device(self, out, twin_out):
-        """clone_to_twin + reset_agent_device + reset_agent_twin_device in one launch."""
-        self._reset_returns()
-        return self.engine.reset_agent_pair(self.twin, out, twin_out)
-
     def step_env_pair_device(self, actions, twin_actions, out, twin_out, last_step=False):
         """One launch for both copies (dcd_mg_step_pair); no reset_random: PAIRED levels come from the teacher."""
         return self.engine.step_pair(self.twin, actions, twin_actions, STEP_LAST if last_step else 0, out, twin_out)

@@ -156,10 +156,6 @@ int dcd_mg_replica(DcdMg* h, int32_t k, DcdMg** out);
  * (adversarial_runner.py:709-733); each rollout starts with reset_agent (:484), so on levels made of walls and a goal
  * (everything the teacher, reset_random and the editor can build) playing two copies side by side is the same game. */
 int dcd_mg_clone_levels(DcdMg* dst, DcdMg* src, void* stream);
-/* dcd_mg_clone_levels(h1, h0) + dcd_mg_reset_agent(h0, out0) + dcd_mg_reset_agent(h1, out1) — the start of PAIRED's two student
- * rollouts on the teacher's levels (adversarial_runner.py:709-733, each agent_rollout begins with reset_agent :484) — in one
- * launch: the envs of h0 are reset, written to BOTH replicas (records, keys, metrics), and observed twice. */
-int dcd_mg_reset_agent_pair(DcdMg* h0, DcdMg* h1, const DcdStudentObs* out0, const DcdStudentObs* out1, void* stream);
 /* venv.set_seed(seeds) → MultiGridEnv.seed (parallel_wrappers.py:414-415,
  * multigrid.py:465-468).  seeds: device int64[B]; resets each env's draw counter. */
 int dcd_mg_set_seed(DcdMg* h, const int64_t* seeds, void* stream);

@@ -226,50 +226,3 @@ def test_wide_workgroup_variants_match_oracle(B, seed):
     x, y = orc.OracleMg(**cfg), HipMg(**cfg)
     mg_diff.compare_state(x, y, "after create")
     mg_diff.drive(x, y, np.random.default_rng(seed), n_calls=9, steps_per_call=12, exotic=True, check_every=3)
-
-
-def test_reset_agent_pair_equals_clone_plus_two_resets():
-    """dcd_mg_reset_agent_pair == dcd_mg_clone_levels + dcd_mg_reset_agent on either replica: records (encodings, state words),
-    metrics, keys (through the next random draws) and both observations, u8 and fp32, after a teacher episode and a few steps."""
-    import torch
-    import dcd_hip
-    B, DEV = 200, "cuda:0"
-    def world():
-        eng = dcd_hip.MultiGridEngine(B, device=DEV, size=15, agent_view_size=5, max_steps=250, max_episode_steps=250, n_clutter=25,
-                                      choose_goal_last=1, random_z_dim=50, replicas=2, engine_seed=5)
-        eng.reset(eng.adv_buffers())
-        loc = dcd_hip.engine.random_actions(B, 0, 2, 0, eng.n_adv_actions, DEV, T=27)
-        for k in range(27):
-            eng.step_adversary(loc[k], eng.adv_buffers())
-        eng.reset_agent()
-        for t in range(5):                                           # move the agents away from their start pose
-            eng.step(dcd_hip.engine.random_actions(B, 0, 3, t, 7, DEV), 0, eng.step_buffers())
-        return eng, eng.replica(1)
-    a, a1 = world()
-    b, b1 = world()
-    oa, oa1 = a.student_buffers(), a1.student_buffers()
-    a.reset_agent_pair(a1, oa, oa1)
-    ob, ob1 = b.student_buffers(), b1.student_buffers()
-    b1.clone_levels(b)
-    b.reset_agent(ob)
-    b1.reset_agent(ob1)
-    torch.cuda.synchronize()
-    for x, y in ((oa, ob), (oa1, ob1), (oa, oa1)):
-        for k in x:
-            assert torch.equal(x[k], y[k]), k
-    for x, y in ((a, b), (a1, b1), (a, a1)):
-        assert torch.equal(x.get_encodings(), y.get_encodings())
-        assert torch.equal(x.get_state(), y.get_state())
-        mx, my = x.get_metrics(), y.get_metrics()
-        assert all(torch.equal(mx[k], my[k]) for k in mx)
-    acts = dcd_hip.engine.random_actions(B, 0, 3, 99, 7, DEV)
-    sa, sa1, sb = a.step_buffers(), a1.step_buffers(), b.step_buffers()
-    a.step(acts, dcd_hip.STEP_RESET_RANDOM, sa); a1.step(acts, dcd_hip.STEP_RESET_RANDOM, sa1); b.step(acts, dcd_hip.STEP_RESET_RANDOM, sb)
-    torch.cuda.synchronize()
-    for k in sa:
-        if isinstance(sa[k], dict):
-            for kk in sa[k]:
-                assert torch.equal(sa[k][kk], sb[k][kk]) and torch.equal(sa1[k][kk], sb[k][kk]), (k, kk)
-        else:
-            assert torch.equal(sa[k], sb[k]) and torch.equal(sa1[k], sb[k]), k
-    assert a.poll_errors()[0] == 0
