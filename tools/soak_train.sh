@@ -16,3 +16,7 @@ run paired --ued_algo=paired --num_env_steps=$((60*4096*256)) && \
 run plr --ued_algo=domain_randomization --use_plr=True --level_replay_prob=0.5 --level_replay_strategy=positive_value_loss \
     --level_replay_seed_buffer_size=4000 --no_exploratory_grad_updates=True --use_editor=True --level_editor_prob=1.0 --num_edits=5 --base_levels=easy \
     --num_env_steps=$((60*4096*256))
+# BASELINE config 3's loop (robust PLR on random-teacher levels stored as action strings), 60 updates
+run robust_plr --ued_algo=domain_randomization --use_plr=True --level_replay_prob=0.5 --level_replay_strategy=positive_value_loss \
+    --level_replay_score_transform=rank --level_replay_temperature=0.3 --staleness_coef=0.3 --level_replay_seed_buffer_size=4000 \
+    --no_exploratory_grad_updates=True --num_env_steps=$((60*4096*256))
