@@ -356,6 +356,36 @@ def sweep_large_b(device, obs="u8", sizes=(65536, 1048576), iters=30):
     return res
 
 
+def fused_steps_leg(B, T, device, K=64, iters=10):
+    """SURVEY §8d's other answer to "the roofline fraction is tiny at B = 4096": multi-step fusion with on-device random
+    actions.  dcd_mg_step_random advances every env K steps per launch — records stay in LDS, actions come from Philox in the
+    kernel, auto-reset on, episode counter kept — and emits the observation / step outputs of the LAST of the K steps only.
+    It shows what the env logic sustains without a kernel boundary per step; it is NOT the benchmark workload (a policy in the
+    loop needs every step's observation) and never enters `value`."""
+    import dcd_hip
+    eng = dcd_hip.MultiGridEngine(B, device=device, n_clutter=25, choose_goal_last=1)
+    eng.reset_random()
+    out = eng.step_buffers(u8=True, f32=False)
+    n_eps = torch.zeros(1, dtype=torch.int64, device=device)
+    launches = max(1, T // K)
+    def rollout(t0):
+        for j in range(launches):
+            eng.step_random(7, t0 + j * K, K, 0, out, n_eps)
+    rollout(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        rollout((i + 1) * T)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    eng.raise_errors()
+    episodes = int(n_eps.item())
+    eng.close()
+    return {"K": K, "launches_per_rollout": launches, "env_steps_per_s": B * launches * K / dt, "us_per_env_step_launch_equivalent": dt / (launches * K) * 1e6,
+            "episodes_counted": episodes,
+            "note": "env logic only, K steps per launch, observation of the last step of each launch; informational, not the benchmark workload"}
+
+
 def end_to_end_leg(B, T, device, updates):
     """SURVEY §8d S_roll / S_train: the same PAIRED config with the PyTorch policy/value nets and PPO in the
     loop (AdversarialRunner.run(): teacher rollout, 2 student rollouts, 3 PPO updates of 5 epochs).  Reported
@@ -509,6 +539,8 @@ def main():
         }
         if sweep is not None:
             line["roofline_large_b"] = sweep
+        if world == 1 and args.sweep:
+            line["s_env_fused_steps"] = fused_steps_leg(B, T, device)
         if grad_leg is not None:
             line["grad_exchange"] = grad_leg
         if not args.no_cpu_baseline and world == 1:
