@@ -254,7 +254,7 @@ def test_batched_scans_equal_the_single_launches():
                 assert torch.equal(x.view(-1), y.view(-1))
 
 
-@pytest.mark.parametrize("T,B,with_scores", [(256, 4096, True), (64, 96, True), (33, 100, True), (64, 256, False)])
+@pytest.mark.parametrize("T,B,with_scores", [(256, 4096, True), (64, 96, True), (33, 100, True), (64, 256, False), (300, 64, True), (129, 32, False)])
 def test_rollout_tail_batch_equals_the_separate_calls(T, B, with_scores):
     """dcd_rollout_tail_batch ({GAE, return statistics, segment counts} of two rollouts side by side in one launch, then the
     scoring) == gae_returns_batch + rollout_return_stats_batch + EpisodeScorer.launch_batch, bit for bit — returns, statistics,
