@@ -283,3 +283,64 @@ int64_t dcd_sampler_draws(int64_t N, int64_t n, const double* w_scores, double c
   flush();
   return n;
 }
+
+
+// ---- per-kernel timing ------------------------------------------------------------------------------------------------------
+#include <atomic>
+#include <mutex>
+namespace dcd {
+namespace {
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
+std::vector<hipEvent_t> g_prof_ev;          // pairs
+std::vector<int> g_prof_tag;                // tag of pair i
+int g_prof_cap = 0;
+}  // namespace
+void prof_pair(int tag, hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_prof_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  const int i = (int)g_prof_tag.size();
+  if (!g_prof_on.load() || i >= g_prof_cap) return;
+  g_prof_tag.push_back(tag);
+  *start = g_prof_ev[2 * i]; *stop = g_prof_ev[2 * i + 1];
+}
+}  // namespace dcd
+
+extern "C" {
+
+int dcd_profile_begin(int32_t capacity) {
+  if (capacity <= 0 || capacity > (1 << 20)) return dcd::fail("dcd_profile_begin: bad capacity %d", capacity);
+  std::lock_guard<std::mutex> lk(dcd::g_prof_mu);
+  while ((int)dcd::g_prof_ev.size() < 2 * capacity) {
+    hipEvent_t e;
+    hipError_t err = hipEventCreate(&e);
+    if (err != hipSuccess) return dcd::fail("dcd_profile_begin: hipEventCreate: %s", hipGetErrorString(err));
+    dcd::g_prof_ev.push_back(e);
+  }
+  dcd::g_prof_tag.clear();
+  dcd::g_prof_cap = capacity;
+  dcd::g_prof_on.store(true);
+  return 0;
+}
+
+int dcd_profile_end(int32_t n_tags, int32_t* n_launches, double* total_ms, double* max_ms, void* stream) {
+  dcd::g_prof_on.store(false);
+  hipError_t err = hipStreamSynchronize((hipStream_t)stream);
+  if (err != hipSuccess) return dcd::fail("dcd_profile_end: hipStreamSynchronize: %s", hipGetErrorString(err));
+  std::lock_guard<std::mutex> lk(dcd::g_prof_mu);
+  for (int t = 0; t < n_tags; ++t) { if (n_launches) n_launches[t] = 0; if (total_ms) total_ms[t] = 0.0; if (max_ms) max_ms[t] = 0.0; }
+  for (size_t i = 0; i < dcd::g_prof_tag.size(); ++i) {
+    const int t = dcd::g_prof_tag[i];
+    if (t < 0 || t >= n_tags) continue;
+    float ms = 0.f;
+    err = hipEventElapsedTime(&ms, dcd::g_prof_ev[2 * i], dcd::g_prof_ev[2 * i + 1]);
+    if (err != hipSuccess) return dcd::fail("dcd_profile_end: hipEventElapsedTime: %s", hipGetErrorString(err));
+    if (n_launches) ++n_launches[t];
+    if (total_ms) total_ms[t] += ms;
+    if (max_ms && ms > max_ms[t]) max_ms[t] = ms;
+  }
+  dcd::g_prof_tag.clear();
+  return 0;
+}
+
+}  // extern "C"

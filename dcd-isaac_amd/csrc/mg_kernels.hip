@@ -678,9 +678,9 @@ template <int OP> static int launch_level(DcdMg* h, const LevelArgs& a, void* st
   if (a.n_rows <= 0) return 0;
   const int epb = step_epb(a.n_rows);
   const dim3 grid((a.n_rows + epb - 1) / epb);
-  if (epb == 16) hipLaunchKernelGGL((mg_level_kernel<OP, 16>), grid, dim3(Threads<16>::value), 0, (hipStream_t)stream, (const uint8_t*)a.rec, a.idx, a.n_rows, h->p, a);
-  else if (epb == 32) hipLaunchKernelGGL((mg_level_kernel<OP, 32>), grid, dim3(Threads<32>::value), 0, (hipStream_t)stream, (const uint8_t*)a.rec, a.idx, a.n_rows, h->p, a);
-  else hipLaunchKernelGGL((mg_level_kernel<OP, 64>), grid, dim3(Threads<64>::value), 0, (hipStream_t)stream, (const uint8_t*)a.rec, a.idx, a.n_rows, h->p, a);
+  if (epb == 16) DCD_LAUNCH_TAGGED(dcd::PROF_LEVEL, (mg_level_kernel<OP, 16>), grid, dim3(Threads<16>::value), (hipStream_t)stream, (const uint8_t*)a.rec, a.idx, a.n_rows, h->p, a);
+  else if (epb == 32) DCD_LAUNCH_TAGGED(dcd::PROF_LEVEL, (mg_level_kernel<OP, 32>), grid, dim3(Threads<32>::value), (hipStream_t)stream, (const uint8_t*)a.rec, a.idx, a.n_rows, h->p, a);
+  else DCD_LAUNCH_TAGGED(dcd::PROF_LEVEL, (mg_level_kernel<OP, 64>), grid, dim3(Threads<64>::value), (hipStream_t)stream, (const uint8_t*)a.rec, a.idx, a.n_rows, h->p, a);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -784,7 +784,7 @@ int dcd_mg_clone_levels(DcdMg* dst, DcdMg* src, void* stream) {
     return dcd::fail("dcd_mg_clone_levels: handles differ in batch, grid size or device");
   if (dst->rec == src->rec) return 0;
   const int B = src->p.B;
-  hipLaunchKernelGGL(clone_kernel, dim3((B * 18 + 255) / 256), dim3(256), 0, (hipStream_t)stream, B,
+  DCD_LAUNCH_TAGGED(dcd::PROF_OTHER, clone_kernel, dim3((B * 18 + 255) / 256), dim3(256), (hipStream_t)stream, B,
                      reinterpret_cast<const uint4*>(src->rec), reinterpret_cast<uint4*>(dst->rec), src->seed, dst->seed,
                      reinterpret_cast<const uint4*>(src->met), reinterpret_cast<uint4*>(dst->met));
   HIP_OK(hipGetLastError());
@@ -884,6 +884,7 @@ static int launch_step(DcdMg* h, int n_sets, const int64_t* actions0, const int6
   if (out1) a.out[1] = *out1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) { e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1]; h->ev_used += 2; }
+  else dcd::prof_pair(dcd::PROF_STEP, &e0, &e1);
   const int epb = step_epb(h->p.B * n_sets);
   const dim3 grid(((h->p.B + epb - 1) / epb) * n_sets);
 #define DCD_LAUNCH_STEP(EPB_, RR_, PAIR_, O8_) hipExtLaunchKernelGGL((mg_step_kernel<false, EPB_, RR_, PAIR_, O8_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, (const uint8_t*)h->rec, (const uint32_t*)h->seed, actions0, h->p.B, actions1, h->p, a)

@@ -11,6 +11,7 @@
 #include <math.h>
 #include <string.h>
 #include "../../include/dcd_hip.h"
+#include <hip/hip_ext.h>
 #include "dcd_internal.h"
 
 namespace {
@@ -204,6 +205,20 @@ __device__ __noinline__ void entropy_reference_lengths_strided(const float* __re
   *mean_out = (float)(acc / (double)(L * A)); *max_out = mx;
 }
 
+// The trailing partial segment (flags == 0, level_sampler.py:551-578) slices `returns[start_t:]` / `value_preds[start_t:]`, which
+// have T + 1 rows where logits and rewards have T: the advantage strategies average over the segment's steps AND row T, while
+// num_steps stays T - start_t.  tail_row adds that element, tail_rows is what it adds to the divisor.
+template <int ST>
+__device__ __forceinline__ int tail_rows(int flags) { return (ST <= DCD_SCORE_SIGNED_VALUE_LOSS && flags == 0) ? 1 : 0; }
+template <int ST>
+__device__ __forceinline__ void tail_row(const ScoreArgs& a, int b, float v_T, SegAcc& sg) {
+  if (ST <= DCD_SCORE_SIGNED_VALUE_LOSS) {
+    float adv = a.ret[(size_t)a.T * a.B + b] - v_T;
+    if (ST == DCD_SCORE_VALUE_L1) adv = fabsf(adv); else if (ST == DCD_SCORE_POSITIVE_VALUE_LOSS) adv = adv > 0.f ? adv : 0.f;
+    sg.acc += adv; sg.mx = adv > sg.mx ? adv : sg.mx;
+  }
+}
+
 template <int ST, bool HAVE_SEED = false>
 __device__ __forceinline__ void flush_segment(const ScoreArgs& a, int b, SegAcc& sg, int end, int flags, int& k) {
   const int L = end - sg.start; constexpr int st = ST;
@@ -222,7 +237,7 @@ __device__ __forceinline__ void flush_segment(const ScoreArgs& a, int b, SegAcc&
       // rows of one env are B*A floats apart: gather the episode's rows through a strided view
       entropy_reference_lengths_strided(a.logits + ((size_t)sg.start * a.B + b) * a.A, (size_t)a.B * a.A, a.A, L,
                                         a.max_entropy, &r.mean_score, &r.max_score);
-    } else { r.mean_score = (float)(sg.acc / (double)L); r.max_score = sg.mx; }
+    } else { r.mean_score = (float)(sg.acc / (double)(L + tail_rows<ST>(flags))); r.max_score = sg.mx; }
     a.recs[k] = r;
   }
   ++k;
@@ -282,7 +297,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) seg_score_kernel(ScoreArgs a) {
       if (t < T) vnext = v1[u];
     }
   }
-  if (sg.start < T) flush_segment<ST>(a, b, sg, T, 0, k);        // trailing partial segment (:551-578)
+  if (sg.start < T) { tail_row<ST>(a, b, vnext, sg); flush_segment<ST>(a, b, sg, T, 0, k); }      // trailing partial segment (:551-578)
 }
 
 // ---- the same segmentation and scoring with the rollout staged in LDS ------------------------------------------
@@ -365,7 +380,7 @@ __device__ __forceinline__ void finish_record(DcdEpisodeRec* slot) {
   else if (ST == DCD_SCORE_ONE_STEP_TD) {
     if (w.len_flags & (1 << 30)) { r.mean_score = (float)w.acc; r.max_score = r.mean_score; }
     else { r.mean_score = (float)(w.acc / (double)(L - 1)); r.max_score = w.mx; }
-  } else { r.mean_score = (float)(w.acc / (double)L); r.max_score = w.mx; }
+  } else { r.mean_score = (float)(w.acc / (double)(L + tail_rows<ST>(r.flags))); r.max_score = w.mx; }
   *slot = r;
 }
 
@@ -481,7 +496,7 @@ __global__ void __launch_bounds__(SNT) seg_score_lds_kernel(ScoreSets sets) {
       }
     }
   }
-  if (tid < SE && sg.start < T) park_segment<ST>(a, b0 + tid, sg, T, 0, k);           // trailing partial segment (:551-578)
+  if (tid < SE && sg.start < T) { tail_row<ST>(a, b0 + tid, vnext, sg); park_segment<ST>(a, b0 + tid, sg, T, 0, k); }   // trailing partial segment (:551-578)
   __syncthreads();                                         // the block's slots [s_range[0], s_range[1]) are parked
   for (int j = s_range[0] + tid; j < min(s_range[1], a.max_recs); j += SNT) finish_record<ST>(a.recs + j);
 }
@@ -612,7 +627,7 @@ int dcd_gae_returns_batch(int32_t n, const float* const* rewards, const float* c
     if (!rewards[k] || !value_preds[k] || !masks[k] || !returns[k]) return dcd::fail("dcd_gae_returns_batch: null pointer in set %d", k);
     sets.rew[k] = rewards[k]; sets.val[k] = value_preds[k]; sets.msk[k] = masks[k]; sets.ret[k] = returns[k];
   }
-  hipLaunchKernelGGL(gae_kernel, dim3(nblk(B), n), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, sets, T, B, (float)gamma,
+  DCD_LAUNCH_TAGGED(dcd::PROF_TAIL, gae_kernel, dim3(nblk(B), n), dim3(SCAN_BLOCK), (hipStream_t)stream, sets, T, B, (float)gamma,
                      (float)(gamma * gae_lambda));
   HIP_OK(hipGetLastError());
   return 0;
@@ -625,14 +640,14 @@ int dcd_gae_returns(const float* rewards, const float* value_preds, const float*
 int dcd_discounted_returns(const float* rewards, const float* value_preds, const float* masks, float* returns, int32_t T, int32_t B,
                            double gamma, void* stream) {
   if (!rewards || !value_preds || !masks || !returns || T <= 0 || B <= 0) return dcd::fail("dcd_discounted_returns: bad arguments");
-  hipLaunchKernelGGL(disc_kernel, dim3(nblk(B)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, rewards, value_preds, masks, returns, T, B, (float)gamma);
+  DCD_LAUNCH_TAGGED(dcd::PROF_TAIL, disc_kernel, dim3(nblk(B)), dim3(SCAN_BLOCK), (hipStream_t)stream, rewards, value_preds, masks, returns, T, B, (float)gamma);
   HIP_OK(hipGetLastError());
   return 0;
 }
 int dcd_batched_value_loss(const float* returns, const float* value_preds, float* out, int32_t T, int32_t B, int32_t mode,
                            int32_t power, int32_t clipped, void* stream) {
   if (!returns || !value_preds || !out || T <= 0 || B <= 0 || mode < 0 || mode > 2) return dcd::fail("dcd_batched_value_loss: bad arguments");
-  hipLaunchKernelGGL(value_loss_kernel, dim3(nblk(B)), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, returns, value_preds, out, T, B, mode, power, clipped);
+  DCD_LAUNCH_TAGGED(dcd::PROF_OTHER, value_loss_kernel, dim3(nblk(B)), dim3(SCAN_BLOCK), (hipStream_t)stream, returns, value_preds, out, T, B, mode, power, clipped);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -683,9 +698,9 @@ static int episode_scores_impl(int32_t n, const DcdEpisodeScoreArgs* q, int32_t 
       sets.counts[k] = counts; sets.block_sums[k] = block_sums; sets.n_recs[k] = q[k].n_recs;
       cs.msk[k] = q[k].masks; cs.counts[k] = counts; cs.block_sums[k] = block_sums;
     }
-    if (!counts_done) hipLaunchKernelGGL(seg_count_par_kernel, dim3((B + 63) / 64, n), dim3(256), 0, s, cs, T, B);
+    if (!counts_done) DCD_LAUNCH_TAGGED(dcd::PROF_COUNT, seg_count_par_kernel, dim3((B + 63) / 64, n), dim3(256), s, cs, T, B);
     switch (strategy) {
-#define DCD_SCORE_CASE(ST) case ST: hipLaunchKernelGGL(seg_score_lds_kernel<ST>, dim3(B / SE, n), dim3(SNT), 0, s, sets); break;
+#define DCD_SCORE_CASE(ST) case ST: DCD_LAUNCH_TAGGED(dcd::PROF_SCORE, seg_score_lds_kernel<ST>, dim3(B / SE, n), dim3(SNT), s, sets); break;
       DCD_SCORE_CASE(0) DCD_SCORE_CASE(1) DCD_SCORE_CASE(2) DCD_SCORE_CASE(6) DCD_SCORE_CASE(7) DCD_SCORE_CASE(8)
 #undef DCD_SCORE_CASE
     }
@@ -694,11 +709,11 @@ static int episode_scores_impl(int32_t n, const DcdEpisodeScoreArgs* q, int32_t 
   }
   for (int k = 0; k < n; ++k) {                       // one env per lane (logit strategies, odd batch sizes): per set
     int* counts = q[k].workspace; int* offsets = q[k].workspace + B;
-    hipLaunchKernelGGL(seg_count_kernel, dim3(nblk(B)), dim3(SCAN_BLOCK), 0, s, q[k].masks, T, B, counts);
-    hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, s, counts, offsets, B, q[k].n_recs);
+    DCD_LAUNCH_TAGGED(dcd::PROF_COUNT, seg_count_kernel, dim3(nblk(B)), dim3(SCAN_BLOCK), s, q[k].masks, T, B, counts);
+    DCD_LAUNCH_TAGGED(dcd::PROF_COUNT, seg_scan_kernel, dim3(1), dim3(1024), s, counts, offsets, B, q[k].n_recs);
     ScoreArgs a; fill(a, q[k]); a.offsets = offsets;
     switch (strategy) {
-#define DCD_SCORE_CASE(ST) case ST: hipLaunchKernelGGL(seg_score_kernel<ST>, dim3(nblk(B)), dim3(SCAN_BLOCK), 0, s, a); break;
+#define DCD_SCORE_CASE(ST) case ST: DCD_LAUNCH_TAGGED(dcd::PROF_SCORE, seg_score_kernel<ST>, dim3(nblk(B)), dim3(SCAN_BLOCK), s, a); break;
       DCD_SCORE_CASE(0) DCD_SCORE_CASE(1) DCD_SCORE_CASE(2) DCD_SCORE_CASE(3) DCD_SCORE_CASE(4)
       DCD_SCORE_CASE(5) DCD_SCORE_CASE(6) DCD_SCORE_CASE(7) DCD_SCORE_CASE(8)
 #undef DCD_SCORE_CASE
@@ -741,7 +756,7 @@ int dcd_rollout_tail_batch(int32_t n, const float* const* rewards, const float* 
     }
   }
   const unsigned gx = (unsigned)((B + 63) / 64);                     // >= ceil(B / 256): the GAE / statistics rows use a prefix of it
-  hipLaunchKernelGGL(rollout_tail_kernel, dim3(n_count ? gx : (unsigned)((B + 255) / 256), 2 * n + n_count), dim3(256), 0, (hipStream_t)stream,
+  DCD_LAUNCH_TAGGED(dcd::PROF_TAIL, rollout_tail_kernel, dim3(n_count ? gx : (unsigned)((B + 255) / 256), 2 * n + n_count), dim3(256), (hipStream_t)stream,
                      gs, ss, cs, n, n_count, T, B, (float)gamma, (float)(gamma * gae_lambda));
   HIP_OK(hipGetLastError());
   if (score) return episode_scores_impl(n, score, T, B, A, strategy, gamma, stream, n_count > 0);
@@ -783,7 +798,7 @@ int dcd_rollout_return_stats_batch(int32_t n, const float* const* ep_ret, const 
     sets.ep_ret[k] = ep_ret[k]; sets.info[k] = info[k]; sets.mean_r[k] = mean_return[k]; sets.max_r[k] = max_return[k];
     sets.n_eps[k] = n_episodes ? n_episodes[k] : nullptr;
   }
-  hipLaunchKernelGGL(return_stats_kernel, dim3(nblk(B), n), dim3(SCAN_BLOCK), 0, (hipStream_t)stream, sets, T, B);
+  DCD_LAUNCH_TAGGED(dcd::PROF_OTHER, return_stats_kernel, dim3(nblk(B), n), dim3(SCAN_BLOCK), (hipStream_t)stream, sets, T, B);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -798,7 +813,7 @@ int dcd_env_return(const float* agent_mean, const float* agent_max, const float*
   if (!agent_max || !out || B <= 0 || mode < 0 || mode > 2) return dcd::fail("dcd_env_return: bad arguments");
   if (mode != 2 && (!agent_mean || !adv_max)) return dcd::fail("dcd_env_return: paired modes need agent_mean and adv_max");
   if (mode == 1 && !adv_mean) return dcd::fail("dcd_env_return: flexible_paired needs adv_mean");
-  hipLaunchKernelGGL(env_return_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, agent_mean, agent_max, adv_mean, adv_max, out, B, mode);
+  DCD_LAUNCH_TAGGED(dcd::PROF_OTHER, env_return_kernel, dim3((B + 255) / 256), dim3(256), (hipStream_t)stream, agent_mean, agent_max, adv_mean, adv_max, out, B, mode);
   HIP_OK(hipGetLastError());
   return 0;
 }

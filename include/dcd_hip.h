@@ -216,6 +216,19 @@ int dcd_mg_step_pair(DcdMg* h0, DcdMg* h1, const int64_t* actions0, const int64_
 int dcd_mg_profile_begin(DcdMg* h, int32_t capacity);
 int dcd_mg_profile_end(DcdMg* h, int32_t* n_launches, double* total_ms, void* stream);
 
+/* Per-kernel timing of a whole hot-path pass (bench.py's `kernel_times`; no reference counterpart — the reference has no
+ * kernels): between begin and end every launch of the pass kernels, from any entry point of this library, carries a HIP
+ * start / stop event pair attached to the dispatch (the kernel's own begin -> end timestamps, as rocprofv3 --kernel-trace
+ * reads them, with no tracer attached).  Tags: 0 mg_step_kernel (dcd_mg_step / dcd_mg_step_pair), 1 mg_level_kernel
+ * (reset / step_adversary / reset_agent / ...), 2 rollout_tail_kernel or gae_kernel (dcd_rollout_tail_batch,
+ * dcd_gae_returns*), 3 seg_score_lds_kernel / seg_score_kernel (dcd_episode_scores*), 4 the segment count / offset
+ * kernels of the scoring when they run as their own launches, 5 return statistics / regret / value loss / clone.
+ * end() synchronises `stream` and fills, per tag t < n_tags: launches, summed and maximum duration in ms.
+ * Process-wide, for measurement runs: do not profile while other host threads launch. */
+#define DCD_PROF_NTAGS 6
+int dcd_profile_begin(int32_t capacity);
+int dcd_profile_end(int32_t n_tags, int32_t* n_launches, double* total_ms, double* max_ms, void* stream);
+
 /* ---- state readback -------------------------------------------------------- */
 /* venv.get_encodings (parallel_wrappers.py:420-421 → adversarial.py:162-164):
  * uint8[B,S,S,3]. */

@@ -401,6 +401,58 @@ def gen_entropy():
     print("entropy.npz", len(out), "calls", len(calls))
 
 
+def gen_staged():
+    """Rollouts at the widths the LDS-staged scoring kernels take (B a multiple of 32; one and two time tiles): T = 256, B = 64
+    and T = 300, B = 96, two rollouts per shape (PAIRED's two students).  Returns through the reference's
+    RolloutStorage.compute_returns (storage.py:233-256), then the (actor, seed, score, max, steps, done) sequence its LevelSampler
+    passes to _partial_update_seed_score (level_sampler.py:486-578) and the sampler state after it, for the value strategies.
+    The logits buffer is all zeros (these strategies ignore it) and is not stored."""
+    from algos import RolloutStorage
+    from level_replay import LevelSampler
+    obs_space, act_space = student_spaces()
+    gamma, lam = 0.995, 0.95
+    out = {"gamma_lambda": np.array([gamma, lam])}
+    strategies = ["positive_value_loss", "value_l1", "signed_value_loss", "one_step_td_error", "grounded_positive_value_loss",
+                  "grounded_signed_value_loss"]
+    for name, (T, B, seed) in {"a0": (256, 64, 31), "a1": (256, 64, 32), "b0": (300, 96, 33), "b1": (300, 96, 34)}.items():
+        rng = np.random.default_rng(seed)
+        d = synth_rollout(rng, T, B, p_done=0.03)
+        d["action_log_dist"] = np.zeros((T, B, 7), np.float32)
+        if name.endswith("1"):                           # second student: some envs end the rollout mid-episode
+            open_end = rng.random((B, 1)) < 0.3
+            d["masks"][T][open_end] = 1.0
+            d["cliffhanger_masks"][T][open_end] = 1.0
+        st = RolloutStorage(None, T, B, obs_space, act_space, 256, recurrent_arch="lstm")
+        fill_storage(st, d)
+        next_value = torch.from_numpy(rng.standard_normal((B, 1)).astype(np.float32))
+        st.compute_returns(next_value, True, gamma, lam)
+        gae = st.returns.clone().numpy()
+        d["value_preds"] = st.value_preds.clone().numpy()      # row T now holds next_value (storage.py:236)
+        for k in ("rewards", "value_preds", "masks", "cliffhanger_masks", "level_seeds"):
+            out[f"{name}_{k}"] = d[k][..., 0]
+        out[f"{name}_gae"] = gae[..., 0]
+        for strat in strategies:
+            calls = []
+            s = LevelSampler(list(range(1, 12)), obs_space, act_space, num_actors=B, strategy=strat, score_transform="rank",
+                             temperature=0.1, staleness_coef=0.3, rho=0.5, replay_prob=0.5, alpha=1.0, gamma=gamma)
+            orig = s._partial_update_seed_score
+
+            def log(actor_index, seed, score, max_score, num_steps, done=False, _o=orig):
+                calls.append((actor_index, seed, float(score), float(max_score), num_steps, int(done)))
+                return _o(actor_index, seed, score, max_score, num_steps, done=done)
+
+            s._partial_update_seed_score = log
+            s.update_with_rollouts(_Rollouts(d, gae))
+            c = np.array(calls, dtype=np.float64)
+            out[f"{name}_{strat}_calls_i"] = c[:, [0, 1, 4, 5]].astype(np.int32)
+            out[f"{name}_{strat}_calls_f"] = c[:, [2, 3]]
+            out[f"{name}_{strat}_seed_scores"] = s.seed_scores.copy()
+            if s.grounded_values is not None:
+                out[f"{name}_{strat}_grounded"] = s.grounded_values.copy()
+    np.savez_compressed(os.path.join(OUT, "staged.npz"), **out)
+    print("staged.npz", len(out), {k: len(out[f"{k}_positive_value_loss_calls_i"]) for k in ("a0", "a1", "b0", "b1")})
+
+
 def gen_popart():
     """models/popart.py:20-103 and its use by RolloutStorage (algos/storage.py:240-256,301-306): moments after three
     updates, normalize / denormalize / forward, GAE returns and batched value loss on denormalised value predictions."""
@@ -537,6 +589,6 @@ if __name__ == "__main__":
     import matplotlib.pyplot  # noqa: F401  (envs/box2d/bezier.py imports it at module level)
     install_shims()
     torch.set_num_threads(1)
-    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy", "popart", "bezier", "f4_nets", "f4_adv"]     # name the sets to (re)generate
+    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy", "popart", "bezier", "f4_nets", "f4_adv", "staged"]     # name the sets to (re)generate
     for name in todo:
         globals()["gen_" + name]()

@@ -118,3 +118,25 @@ def test_regret_modes():
     fp = orc.env_return(*a, mode=1)
     exp = np.where(a[3] > a[1], a[3] - a[0], a[1] - a[2])
     np.testing.assert_array_equal(fp, np.maximum(exp, 0).astype(np.float32))
+
+
+STAGED = dict(positive_value_loss=1, value_l1=0, signed_value_loss=2, one_step_td_error=6)
+
+
+@pytest.mark.parametrize("name", ["a0", "a1", "b0", "b1"])
+def test_staged_width_rollouts_vs_reference(name):
+    """tests/golden/staged.npz: T = 256 / B = 64 and T = 300 / B = 96 (the widths the LDS-staged kernels take), GAE through the
+    reference's RolloutStorage and the call sequence of its LevelSampler — pins the oracle at those shapes too."""
+    g = np.load(os.path.join(G, "staged.npz"))
+    gamma, lam = g["gamma_lambda"]
+    r, v, m = g[f"{name}_rewards"], g[f"{name}_value_preds"], g[f"{name}_masks"]
+    assert np.array_equal(bits(orc.gae_returns(r, v, m, gamma, lam)[:-1]), bits(g[f"{name}_gae"][:-1]))
+    for strategy, code in STAGED.items():
+        recs = orc.episode_scores(g[f"{name}_gae"], v, r, m, g[f"{name}_cliffhanger_masks"], g[f"{name}_level_seeds"], None, code, gamma)
+        keep = recs[(recs["flags"] & 2) == 0]
+        ci, cf = g[f"{name}_{strategy}_calls_i"], g[f"{name}_{strategy}_calls_f"]
+        assert len(keep) == len(ci) > 400
+        assert np.array_equal(keep["actor"], ci[:, 0]) and np.array_equal(keep["seed"], ci[:, 1])
+        assert np.array_equal(keep["num_steps"], ci[:, 2]) and np.array_equal(keep["flags"] & 1, ci[:, 3])
+        np.testing.assert_allclose(keep["mean_score"], cf[:, 0], rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(keep["max_score"], cf[:, 1], rtol=1e-6, atol=1e-7)

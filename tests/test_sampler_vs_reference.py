@@ -249,3 +249,22 @@ def test_native_draw_loop_paths_and_early_stops():
     st, idx = st0.copy(), np.zeros(4, dtype=np.int64)
     k = L.dcd_sampler_draws(C.c_int64(N), C.c_int64(4), p_(wsc), C.c_double(0.3), p_(st), p_(keep), p_(u), C.c_int32(1), p_(idx))
     assert k == 0 and np.array_equal(st, st0)                          # z = 0 at the first draw: nothing drawn, nothing aged
+
+
+@pytest.mark.parametrize("name", ["a0", "a1", "b0", "b1"])
+@pytest.mark.parametrize("strategy", ["positive_value_loss", "one_step_td_error", "grounded_positive_value_loss", "grounded_signed_value_loss"])
+def test_staged_width_rollouts_sampler_state_matches_reference(name, strategy):
+    """tests/golden/staged.npz (T = 256 / B = 64, T = 300 / B = 96; "…1": envs whose rollout ends mid-episode): sampler state after
+    update_with_rollouts, incl. the grounded strategies' host-side advantage and the trailing-partial-segment rule."""
+    from level_replay import LevelSampler
+    g = np.load(os.path.join(G, "staged.npz"))
+    d = {k: g[f"{name}_{k}"] for k in ("rewards", "value_preds", "masks", "cliffhanger_masks", "level_seeds", "gae")}
+    B = d["rewards"].shape[1]
+    recs = orc.episode_scores(d["gae"], d["value_preds"], d["rewards"], d["masks"], d["cliffhanger_masks"], d["level_seeds"], None,
+                              CODES[strategy], float(g["gamma_lambda"][0]))
+    ls = LevelSampler(list(range(1, 12)), None, _Space(), num_actors=B, strategy=strategy, score_transform="rank", temperature=0.1,
+                      staleness_coef=0.3, rho=0.5, replay_prob=0.5, alpha=1.0, gamma=float(g["gamma_lambda"][0]))
+    ls.update_with_records(recs, values=d["value_preds"])
+    np.testing.assert_allclose(ls.seed_scores, g[f"{name}_{strategy}_seed_scores"], rtol=3e-6, atol=3e-7)
+    if ls.grounded_values is not None:
+        np.testing.assert_allclose(ls.grounded_values, g[f"{name}_{strategy}_grounded"], rtol=3e-6, atol=3e-7)
