@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--no-pair", action="store_true", help="step the two students' env copies in two launches per step instead of one")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the end-to-end PAIRED leg (policy nets + PPO in the loop)")
     ap.add_argument("--train-updates", type=int, default=3, help="timed AdversarialRunner.run() calls of the end-to-end leg")
+    ap.add_argument("--profile-out", default=None, help="also write the per-kernel HIP-event times as JSON to this path (profiles/rNN_kernel_event_times.json)")
+    ap.add_argument("--rccl-single", action="store_true",
+                    help="with --gpus 1: create a 1-rank NCCL (= RCCL) process group anyway and run the score all-gather and the gradient "
+                         "all-reduce leg through it (exercises the collective code path on one GPU)")
     return ap.parse_args()
 
 
@@ -237,8 +241,8 @@ def cpu_baseline(B, T, budget_s):
     actions, full StepOut written each step.  A reported baseline, not the target."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import orc
-    cores = len(os.sched_getaffinity(0))
-    nt = max(1, min(16, cores))
+    cores = len(os.sched_getaffinity(0))        # every host core this process may run on (BASELINE.md §3), stated beside nproc
+    nt = max(1, cores)
     m = orc.OracleMg(num_envs=B, n_clutter=25, choose_goal_last=1)
     m.reset()
     for k in range(27):
@@ -254,9 +258,9 @@ def cpu_baseline(B, T, budget_s):
             steps += B * T
             rolls += 1
             m.reset_agent()
-    return dict(value=steps / t_used, unit="env-steps/s", cores=nt, kind="port",
-                sample=f"{rolls} student rollouts of {B} envs x {T} steps (oracle C port, {nt} threads, "
-                       f"{t_used:.1f}s wall, full StepOut incl. fp32 obs)")
+    return dict(value=steps / t_used, unit="env-steps/s", cores=nt, nproc=os.cpu_count(), kind="port",
+                sample=f"{rolls} student rollouts of {B} envs x {T} steps (oracle C port, {nt} threads = every core of "
+                       f"sched_getaffinity, nproc {os.cpu_count()}, {t_used:.1f}s wall, full StepOut incl. fp32 obs)")
 
 
 def py_subproc_baseline(seconds=3.0):
@@ -285,7 +289,7 @@ def py_subproc_baseline(seconds=3.0):
         dt = time.perf_counter() - t0
     finally:
         v.close()
-    return dict(value=steps / dt, unit="env-steps/s", cores=n, kind="port",
+    return dict(value=steps / dt, unit="env-steps/s", cores=n, nproc=os.cpu_count(), kind="port",
                 sample=f"{steps} steps, {n} worker processes x 1 env, pure-Python object-per-cell MultiGrid over pipes, {dt:.1f}s wall")
 
 
@@ -302,7 +306,12 @@ def pmc_traffic(kernel_name, path=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
     this command (tools/pmc_traffic.py; counters need their own profiler runs, they cannot be read from inside the
     benchmark).  Reported only when the file was taken on THIS kernel: same template instance, same source hash."""
-    path = path or os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if path is None:                              # the newest round's file
+        import glob
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+        if not found:
+            return None, "no PMC file"
+        path = found[-1]
     if not os.path.exists(path):
         return None, "no PMC file"
     d = json.load(open(path))
@@ -329,6 +338,32 @@ def step_kernel_profile(ps, n=256):
             ps.eng.step(p["actions"][tt], 0, outs(p, tt))
     launches, ms = ps.eng.profile_end()
     return ms / max(launches, 1) * 1e-3          # seconds per launch
+
+
+PASS_KERNELS = ("mg_step_kernel", "mg_level_kernel", "rollout_tail_kernel", "seg_score_lds_kernel", "seg_count (own launch)", "other (clone, regret)")
+
+
+def pass_kernel_times(ps, passes=3):
+    """HIP-event begin -> end durations of EVERY kernel of the pass (dcd_profile_begin / dcd_profile_end: start / stop events
+    attached to each dispatch by hipExtLaunchKernelGGL, no tracer attached), over `passes` eager passes of the benchmark
+    workload on the current stream.  Per kernel: launches per pass, average and maximum duration; `sum_ms_per_pass` is what the
+    pass would take with no gap between kernels — it must not exceed the measured `ms_per_step`."""
+    import ctypes as C
+    lib = ps.dcd_hip.lib()
+    n = len(PASS_KERNELS)
+    ps.dcd_hip.check(lib.dcd_profile_begin(C.c_int32(passes * 512)))
+    for _ in range(passes):
+        ps.run()
+    cnt, tot, mx = (C.c_int32 * n)(), (C.c_double * n)(), (C.c_double * n)()
+    ps.dcd_hip.check(lib.dcd_profile_end(C.c_int32(n), cnt, tot, mx, ps.dcd_hip.stream_ptr()))
+    out, total = {}, 0.0
+    for k, name in enumerate(PASS_KERNELS):
+        if cnt[k]:
+            out[name] = {"launches_per_pass": cnt[k] / passes, "avg_us": tot[k] / cnt[k] * 1e3, "max_us": mx[k] * 1e3,
+                         "ms_per_pass": tot[k] / passes}
+            total += tot[k] / passes
+    return {"how": "HIP start/stop events on each dispatch (hipExtLaunchKernelGGL), eager launches, no profiler attached",
+            "passes": passes, "kernels": out, "sum_ms_per_pass": total}
 
 
 def sweep_large_b(device, obs="u8", sizes=(65536, 1048576), iters=30):
@@ -451,9 +486,13 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or args.rccl_single:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -472,7 +511,7 @@ def main():
             with torch.cuda.graph(graph, stream=stream):
                 ps.run()
 
-        exchange = ScoreExchange(ps, world) if world > 1 else None
+        exchange = ScoreExchange(ps, world) if dist is not None else None
 
         def one_pass():
             if graph is not None:
@@ -504,6 +543,7 @@ def main():
         n_recs = [int(a["scorer"].n_recs.item()) for a in ps.agents]
         episodes = [int(a["n_eps"].sum().item()) for a in ps.agents]
         kernel_s = step_kernel_profile(ps) if rank == 0 else None
+        kernel_times = pass_kernel_times(ps) if rank == 0 else None
         grad_leg = None
         if dist is not None and args.dist_backend == "nccl":
             try:
@@ -529,7 +569,7 @@ def main():
                                    "Philox uniform actions, N(0,1) value predictions, no policy nets; both students' env copies "
                                    "advance in one launch per step; observations written as " + ("raw u8 encodings" if ps.obs == "u8" else "fp32 CHW / 10"),
                        "envs_per_gpu": B, "num_steps": T, "teacher_steps": ps.Tadv, "grid": "15x15", "view": "5x5",
-                       "hip_graph": graph is not None, "parallelism": f"env-sharded x{world}",
+                       "hip_graph": graph is not None, "parallelism": f"env-sharded x{world}" + (" (1-rank RCCL group: score all-gather per pass)" if args.rccl_single and world == 1 else ""),
                        "env_steps_per_pass_per_gpu": ps.steps_per_pass(),
                        "episode_records_last_pass": n_recs, "episodes_last_pass": episodes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -537,6 +577,15 @@ def main():
                          "envs_per_launch": rows, "algorithmic_bytes_per_launch": algo, "avg_launch_us": kernel_s * 1e6,
                          "note": f"one launch moves {algo / 1e6:.2f} MB: latency-bound at this batch (DESIGN.md §3); roofline_large_b: the same kernel where it is HBM-bound"},
         }
+        kernel_times["ms_per_step_measured"] = dt / args.steps * 1e3
+        kernel_times["fits"] = kernel_times["sum_ms_per_pass"] <= dt / args.steps * 1e3
+        line["kernel_times"] = kernel_times
+        line["roofline"]["timing"] = ("avg_launch_us: HIP start/stop events on each mg_step_kernel dispatch over one eager student rollout "
+                                      "(step_kernel_profile); kernel_times lists the same measurement for every kernel of the pass")
+        if args.profile_out:
+            with open(args.profile_out, "w") as f:
+                json.dump({"bench_py_args": sys.argv[1:], "ms_per_step": dt / args.steps * 1e3, "roofline_kernel": kernel_name,
+                           "roofline_avg_launch_us": kernel_s * 1e6, "kernel_times": kernel_times}, f, indent=1)
         if sweep is not None:
             line["roofline_large_b"] = sweep
         if world == 1 and args.sweep:

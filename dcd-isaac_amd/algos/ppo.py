@@ -25,8 +25,10 @@ class PPO:
         self.optimizer = optim.Adam(actor_critic.parameters(), lr=lr, eps=eps)
         self.log_grad_norm = log_grad_norm
         self.process_group = process_group
+        # a group of ONE rank runs every exchange step too (each is then the identity, bit for bit): the RCCL path on a one-GPU box
+        self.distributed = process_group is not None
         self._flat_grad = None
-        if self.world_size > 1:                                      # ranks seed differently (env streams): start from rank 0's weights
+        if self.distributed:                                         # ranks seed differently (env streams): start from rank 0's weights
             import torch.distributed as dist
             src = dist.get_global_rank(process_group, 0)
             for t in list(actor_critic.parameters()) + list(actor_critic.buffers()):
@@ -47,16 +49,24 @@ class PPO:
         return t
 
     def _normalize_advantages(self, adv):
-        """(adv - mean) / (std + 1e-5) with unbiased std (ppo.py:67-69), moments over ALL ranks."""
-        if self.world_size == 1:
+        """(adv - mean) / (std + 1e-5) with unbiased std (ppo.py:67-69), moments over ALL ranks: every rank contributes
+        (n, mean, std) of its own slice — torch's own fp32 reductions, the single-process arithmetic — as one row of a
+        [world, 3] fp64 tensor (ONE all-reduce = an all-gather), and the rows are merged exactly as parallel-variance
+        merging prescribes: mean = sum n_i mean_i / N, M2 = sum (n_i - 1) var_i + sum n_i (mean_i - mean)^2.  With one rank
+        the merge returns that rank's mean and std bit for bit, so a 1-rank group equals the run without a group."""
+        if not self.distributed:
             return (adv - adv.mean()) / (adv.std() + 1e-5)
-        s = torch.stack([adv.sum().double(), (adv.double() ** 2).sum(),
-                         torch.tensor(float(adv.numel()), dtype=torch.float64, device=adv.device)])
-        self._all_reduce(s)
-        n = s[2]
-        mean = s[0] / n
-        var = (s[1] - n * mean * mean) / (n - 1)
-        return (adv - mean.float()) / (var.clamp_min(0).sqrt().float() + 1e-5)
+        import torch.distributed as dist
+        rows = torch.zeros((self.world_size, 3), dtype=torch.float64, device=adv.device)
+        rows[dist.get_rank(self.process_group)] = torch.stack([torch.tensor(float(adv.numel()), dtype=torch.float64, device=adv.device),
+                                                               adv.mean().double(), adv.std().double()])
+        self._all_reduce(rows)
+        n, m, sd = rows[:, 0], rows[:, 1], rows[:, 2]
+        total = n.sum()
+        mean = (n * m).sum() / total
+        m2 = ((n - 1) * sd * sd).sum() + (n * (m - mean) ** 2).sum()
+        std = (m2 / (total - 1)).clamp_min(0).sqrt()
+        return (adv - mean.float()) / (std.float() + 1e-5)
 
     # ---- gradient exchange (no counterpart in the reference: one process there) ------------------------------------
     # Every parameter's .grad is a VIEW into one persistent flat buffer (no cat / copy-back per minibatch: two passes over
@@ -87,7 +97,7 @@ class PPO:
         self._flat_grad, self._flat_params, self._bucket_bounds = flat, order, bounds
         self._bucket_need, self._bucket_of = need, touching
         self._bucket_left, self._handles, self._launched = list(need), [], [False] * nb
-        if self.world_size > 1:
+        if self.distributed:
             for i, p in enumerate(order):
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self._grad_ready(i))
 
@@ -123,7 +133,7 @@ class PPO:
         """Launches what the hooks did not (the final bucket with the statistics in its tail; buckets whose parameters
         received no gradient), waits, averages.  Returns the job-wide means of `stats` (value loss, action loss,
         entropy) — they cost no collective of their own."""
-        if self.world_size == 1:
+        if not self.distributed:
             return stats
         self._flat_grad[-3:].copy_(stats)
         for b in range(len(self._bucket_bounds)):
@@ -158,7 +168,7 @@ class PPO:
                 surr2 = torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_b
                 action_loss = -torch.min(surr1, surr2).mean()
                 if rollouts.use_popart:                              # ppo.py:102-104: targets in PopArt's normalised space
-                    self.actor_critic.popart.update(return_b)
+                    self.actor_critic.popart.update(return_b, group=self.process_group)   # job-wide batch moments
                     return_b = self.actor_critic.popart.normalize(return_b)
                 if self.clip_value_loss:
                     clipped = value_preds_b + (values - value_preds_b).clamp(-self.clip_param, self.clip_param)

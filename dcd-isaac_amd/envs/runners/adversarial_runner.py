@@ -54,13 +54,16 @@ class AdversarialRunner:
         self.args = args
         self.process_group = process_group
         self.world_size = 1
+        # a group of ONE rank takes the same code path as a group of eight — every collective runs (as the identity): that is how
+        # the RCCL path is exercised on a one-GPU box (tests/test_gpu_rccl_single.py)
+        self.distributed = process_group is not None
         if process_group is not None:
             import torch.distributed as dist
             self.world_size = dist.get_world_size(process_group)
         self.venv = venv
         self.ued_venv = venv if ued_venv is None else ued_venv
         self._pending_updates, self._update_streams, self._deferred_host = [], [], []
-        self._concurrent_updates = (self.world_size == 1 and os.environ.get("DCD_CONCURRENT_PPO", "1") != "0")
+        self._concurrent_updates = (not self.distributed and os.environ.get("DCD_CONCURRENT_PPO", "1") != "0")
         self.is_discrete_actions = is_discrete_actions(self.venv)
         self.is_discrete_adversary_env_actions = is_discrete_actions(self.venv, adversary=True)
         self.agents = {"agent": agent, "adversary_agent": adversary_agent, "adversary_env": adversary_env}
@@ -84,7 +87,7 @@ class AdversarialRunner:
         self.weighted_num_edits = 0
         self.latest_env_stats = defaultdict(float)
         if plr_args:
-            if self.world_size > 1:
+            if self.distributed:
                 from level_replay.sharded import ShardedLevelSampler, ShardedLevelStore
                 make_sampler = lambda: ShardedLevelSampler(plr_args, group=process_group)
                 make_store = lambda **kw: ShardedLevelStore(group=process_group, **kw)
@@ -191,7 +194,7 @@ class AdversarialRunner:
             setattr(self, key, sd.get(key))
         self._table = None                                            # the device mirror of the (replaced) level store refills lazily
         if self.args.use_plr:
-            if self.world_size > 1:                                   # checkpoint written by rank 0: re-attach the group
+            if self.distributed:                                      # checkpoint written by rank 0: re-attach the group
                 import torch.distributed as dist
                 self.level_store.group = self.process_group
                 for s in self.all_level_samplers:
@@ -240,10 +243,19 @@ class AdversarialRunner:
     def _get_plr_buffer_stats(self):
         stats = {}
         for k, s in self.level_samplers.items():
-            stats[k + "_plr_passable_mass"] = s.solvable_mass
+            stats[k + "_plr_passable_mass"] = self._logged(lambda: s.solvable_mass)
             stats[k + "_plr_max_score"] = s.max_score
             stats[k + "_plr_weighted_num_edits"] = self.weighted_num_edits
         return stats
+
+    @staticmethod
+    def _logged(fn):
+        """A logging-only read of the replay distribution.  While every buffer slot is still unseen the reference's
+        `weights /= np.sum(weights)` (level_sampler.py:736) is 0/0: it warns and logs NaN.  The sampler's arithmetic is kept;
+        the LOGGED value of an empty buffer is 0.0 and no warning is raised."""
+        with np.errstate(invalid="ignore", divide="ignore"):
+            v = fn()
+        return 0.0 if isinstance(v, float) and v != v else (0.0 if isinstance(v, np.floating) and np.isnan(v) else v)
 
     def _get_env_stats(self, agent_info, adversary_agent_info, log_replay_complexity=False):
         if not self.args.env_name.startswith("MultiGrid"):
@@ -273,7 +285,7 @@ class AdversarialRunner:
 
     def _from_rank0(self, value):
         """Host-side random decisions must agree on every rank: rank 0's draw wins (one small tensor broadcast)."""
-        if self.world_size == 1:
+        if not self.distributed:
             return value
         from util import distributed as D
         return bool(D.broadcast_ints([int(bool(value))], 1, group=self.process_group, device=self.device)[0])
@@ -312,7 +324,7 @@ class AdversarialRunner:
         n = np.zeros(sampler.seed_buffer_size)
         for idx, value in enumerate(self.level_store.seed2parent.values()):
             n[idx] = len(value)
-        return np.dot(sampler.sample_weights(), n)
+        return self._logged(lambda: np.dot(sampler.sample_weights(), n))
 
     def _sample_replay_decision(self):
         return self._default_level_sampler.sample_replay_decision()
@@ -400,11 +412,13 @@ class AdversarialRunner:
 
     # ---- rollouts --------------------------------------------------------------------------------
     # Rollout steps per HIP graph.  A whole rollout is ONE graph: a fused 256-step student rollout is ~1.5k kernel nodes, a
-    # rollout of PyTorch modules ~12k; graphs of 100k kernel nodes capture and replay correctly on ROCm 7.2, at ~160k
-    # hipStreamEndCapture crashes on the host (tools/graph_assert_probe.py), hence the cap for very long rollouts.  (Round 1
-    # chunked to 32 steps after a GPU abort "with 10k-node graphs"; the abort had nothing to do with graph size — see
-    # models/distributions.py::FixedCategorical.sample and DESIGN.md §8.)
-    GRAPH_CHUNK = 2048
+    # rollout of PyTorch modules (DCD_HIP_GRAPHS=2) ~45 nodes per step.  The largest capture on record that works on ROCm 7.2
+    # is 48 000 kernel nodes; at 80 000 and 120 000 hipStreamEndCapture crashes on the host
+    # (profiles/r02_graph_abort_root_cause.log §4, tools/graph_assert_probe.py), so the cap keeps the worst case — a module
+    # rollout — below 40k nodes per graph: 800 steps x ~45 nodes = 36k.  (Round 1 chunked to 32 steps after a GPU abort "with
+    # 10k-node graphs"; the abort had nothing to do with graph size — see models/distributions.py::FixedCategorical.sample
+    # and DESIGN.md §8.)
+    GRAPH_CHUNK = 800
 
     def _graphed(self, key, num_steps, fn):
         """fn(t0, t1) issues rollout steps [t0, t1).  First call: eager (warm-up); second: captured (one HIP graph per
@@ -874,7 +888,7 @@ class AdversarialRunner:
                                           adv["max_return"], mode=mode)
         if args.adv_normalize_returns:
             sample = env_return.flatten()
-            if self.world_size > 1:                 # moments of the whole job's batch, in global env order
+            if self.distributed:                    # moments of the whole job's batch, in global env order
                 import torch.distributed as dist
                 parts = [torch.empty_like(sample) for _ in range(self.world_size)]
                 dist.all_gather(parts, sample.contiguous(), group=self.process_group)

@@ -52,12 +52,22 @@ class PopArt(DeviceAwareModule):
         return F.linear(self._tensor(x), self.weight, self.bias)
 
     @torch.no_grad()
-    def update(self, returns):
+    def update(self, returns, group=None):
+        """`group` (not in the reference: one process there): the batch moments are averaged over its ranks — equal minibatch
+        sizes on every rank, so the mean of the per-rank means is the mean over the job-wide minibatch — and every rank moves
+        its (replicated) PopArt state by the same amount.  One rank: x / 1, the plain update bit for bit."""
         x = self._tensor(returns)
         axes = tuple(range(self.norm_axes))
         keep = 1.0 - self.beta
-        self.mean.mul_(self.beta).add_(x.mean(dim=axes) * keep)
-        self.mean_sq.mul_(self.beta).add_((x ** 2).mean(dim=axes) * keep)
+        batch_mean, batch_mean_sq = x.mean(dim=axes), (x ** 2).mean(dim=axes)
+        if group is not None:
+            import torch.distributed as dist
+            mom = torch.stack([batch_mean, batch_mean_sq])
+            dist.all_reduce(mom, group=group)
+            mom /= dist.get_world_size(group)
+            batch_mean, batch_mean_sq = mom[0], mom[1]
+        self.mean.mul_(self.beta).add_(batch_mean * keep)
+        self.mean_sq.mul_(self.beta).add_(batch_mean_sq * keep)
         self.debiasing_term.mul_(self.beta).add_(1.0 * keep)
         self.stddev.data = (self.mean_sq - self.mean ** 2).sqrt().clamp(min=1e-4)
         # the reference's output-preserving step with its aliased "old" moments (see module docstring)

@@ -62,6 +62,25 @@ def safe_checkpoint(state_dict, path, index=None, archive_interval=None):
         shutil.copy(path, f"{filename}_{index}{ext}")
 
 
+def load_checkpoint_safe(path, map_location=None):
+    """torch.load of a `model.tar` without running anything the file names: `weights_only=True`, with an allow-list of exactly
+    the non-tensor types a runner checkpoint holds (adversarial_runner.py:203-216 pickles the LevelSampler / LevelStore objects
+    and their numpy arrays next to the state dicts; the module paths are the reference's, so its checkpoints name the same
+    classes).  A file that names anything else is refused with torch's UnpicklingError — it is not executed."""
+    import collections
+    import numpy as np
+    from level_replay.level_sampler import LevelSampler
+    from level_replay.level_store import LevelStore
+    from level_replay.sharded import ShardedLevelSampler, ShardedLevelStore
+    from envs import spaces
+    allow = [LevelSampler, LevelStore, ShardedLevelSampler, ShardedLevelStore, spaces.Box, spaces.Discrete, spaces.Dict, collections.defaultdict, collections.OrderedDict,
+             collections.deque, set, frozenset, float, int, list, dict, tuple, str, bool, np.ndarray, np.dtype, np._core.multiarray._reconstruct, np._core.multiarray.scalar]
+    allow += [np.float64, np.float32, np.int64, np.int32, np.int16, np.int8, np.uint64, np.uint32, np.uint16, np.uint8, np.bool_]
+    allow += sorted({type(np.dtype(t)) for t in ("f8", "f4", "i8", "i4", "i2", "i1", "u8", "u4", "u2", "u1", "?", "O", "S1", "U1")}, key=repr)
+    with torch.serialization.safe_globals(allow):
+        return torch.load(path, map_location=map_location, weights_only=True)
+
+
 def save_images(images, path=None, normalize=False, channels_first=False, nrow=8, padding=2):
     """Tile `images` (list of HWC uint8 arrays) into one grid image and write it as PNG (reference: util/__init__.py
     save_images -> torchvision make_grid/save_image, 8 per row, 2-pixel black padding; torchvision is not a

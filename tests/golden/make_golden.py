@@ -582,6 +582,70 @@ def gen_f4_adv():
     print("f4_adv.npz", len(out))
 
 
+def gen_f4_cr_adv():
+    """models/car_racing_models.py:168-530 CarRacingBezierAdversaryEnvNetwork (the level builder of BASELINE config 5), spaces as
+    envs/box2d/car_racing_adversarial.py:58-127 builds them (10 x 10 sketch, 12 control points, random_z 50): initial weights from
+    a fixed seed (digests), then get_value / evaluate_actions on fixed inputs and act under a fixed torch seed, for the continuous
+    (Beta) form, the categorical form with the skip action, and the sparse-reward form with a goal-bin step (+ PopArt)."""
+    from models.car_racing_models import CarRacingBezierAdversaryEnvNetwork
+    rng = np.random.default_rng(33)
+    out = {}
+    cases = {"beta": (dict(), 12, False), "cat": (dict(use_categorical=True, use_skip=True), 12, False),
+             "goal": (dict(use_categorical=True, use_skip=True, use_goal=True, num_goal_bins=24, use_popart=True), 13, True)}
+    for tag, (kw, max_steps, goal) in cases.items():
+        obs = {"control_points": Box((1, 10, 10), high=10), "time_step": Box((1,), high=max_steps), "random_z": Box((50,), high=1)}
+        if goal:
+            obs["goal_bin"] = Box((1,), high=25)
+        if kw.get("use_categorical"):
+            act = Box((2,) if goal else (1,))
+            act.high = np.array((1, 101)) if goal else np.array((101,))
+        else:
+            act = Box((3,), high=1)
+        torch.manual_seed(0)
+        net = CarRacingBezierAdversaryEnvNetwork(obs, act, **kw)
+        out.update({f"{tag}_w_{k}": _digest(p) for k, p in net.state_dict().items()})
+        B = 6
+        sketch = (rng.random((B, 1, 10, 10)) < 0.06).astype(np.float32)
+        sketch[0] = 0                                                      # an empty sketch: fewer than 3 points, skip masked
+        ts = rng.integers(0, max_steps - 1, (B, 1)).astype(np.float32)
+        if goal:
+            ts[4] = max_steps - 1                                          # ONE goal step in the batch (time_step == total - 1)
+        x = {"control_points": sketch, "time_step": ts, "random_z": rng.random((B, 50)).astype(np.float32)}
+        if goal:
+            x["goal_bin"] = np.full((B, 1), 24, np.float32)
+        xt = {k: torch.from_numpy(v) for k, v in x.items()}
+        if kw.get("use_categorical"):
+            free = [np.flatnonzero(sketch[b].ravel() == 0) + 1 for b in range(B)]
+            a = np.array([[float(rng.choice(f))] for f in free], np.float32)
+            if goal:
+                a[4] = 7.0
+                a = np.concatenate([(ts == max_steps - 1).astype(np.float32), a], axis=1)
+        else:
+            a = (rng.random((B, 3)) * 0.96 + 0.02).astype(np.float32)
+        with torch.no_grad():
+            v, lp, ent, _ = net.evaluate_actions(xt, None, None, torch.from_numpy(a))
+            gv = net.get_value(xt, None, None)
+            # act: every row of a batch is at the same step (it reads time_step[0]); a fixed torch seed fixes the draw
+            one = {k: t.clone() for k, t in xt.items()}
+            one["time_step"][:] = 3.0
+            torch.manual_seed(5)
+            av, aa, alp, _ = net.act(one, None, None)
+            out.update({f"{tag}_act_value": av.numpy(), f"{tag}_act_action": aa.numpy().astype(np.float64), f"{tag}_act_logp": alp.numpy()})
+            if goal:
+                one["time_step"][:] = float(max_steps - 1)
+                torch.manual_seed(6)
+                gvv, ga, glp, _ = net.act(one, None, None)
+                out.update({f"{tag}_gact_action": ga.numpy().astype(np.float64), f"{tag}_gact_logp": glp.numpy()})
+                out[f"{tag}_proc_goal"] = net.process_action(ga).numpy().astype(np.float64)
+            if kw.get("use_categorical"):
+                out[f"{tag}_proc"] = net.process_action(aa).numpy().astype(np.float64)
+        out.update({f"{tag}_x_{k}": v_ for k, v_ in x.items()})
+        out.update({f"{tag}_a": a, f"{tag}_value": v.numpy(), f"{tag}_logp": lp.numpy(), f"{tag}_ent": np.array(float(ent)),
+                    f"{tag}_get_value": gv.numpy()})
+    np.savez_compressed(os.path.join(OUT, "f4_cr_adv.npz"), **out)
+    print("f4_cr_adv.npz", len(out))
+
+
 if __name__ == "__main__":
     import numpy.ma  # noqa: F401  (must be imported BEFORE the alias shims: numpy 2 uses np.bool as a dtype there)
     import matplotlib
@@ -589,6 +653,6 @@ if __name__ == "__main__":
     import matplotlib.pyplot  # noqa: F401  (envs/box2d/bezier.py imports it at module level)
     install_shims()
     torch.set_num_threads(1)
-    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy", "popart", "bezier", "f4_nets", "f4_adv", "staged"]     # name the sets to (re)generate
+    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy", "popart", "bezier", "f4_nets", "f4_adv", "staged", "f4_cr_adv"]     # name the sets to (re)generate
     for name in todo:
         globals()["gen_" + name]()

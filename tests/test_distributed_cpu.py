@@ -196,7 +196,7 @@ def _teacher_return(runner_cls, info, adv_info, world, group, updates):
     from dcd_hip import scans
     from envs.runners.adversarial_runner import RunningMeanStd
     args = types.SimpleNamespace(ued_algo="paired", adv_normalize_returns=True, adv_clip_reward=None)
-    me = types.SimpleNamespace(args=args, is_paired=True, world_size=world, process_group=group, env_return_rms=RunningMeanStd(shape=()))
+    me = types.SimpleNamespace(args=args, is_paired=True, world_size=world, distributed=group is not None, process_group=group, env_return_rms=RunningMeanStd(shape=()))
     keep, scans.env_return = scans.env_return, _paired_regret        # collective logic only: no GPU in this test
     try:
         for u in range(updates):
@@ -239,3 +239,72 @@ def test_sharded_adv_normalize_returns_uses_job_wide_moments():
         got = torch.load(out, weights_only=True)
     assert got["mean"] == float(rms.mean) and got["var"] == float(rms.var) and got["count"] == float(rms.count)
     assert torch.equal(got["ret"], want)
+
+
+def _one_rank_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    g = np.load(os.path.join(G, "ppo.npz"))
+    agent, net = _build(g, [0, 1, 2, 3], dist.group.WORLD)
+    assert agent.algo.distributed and agent.algo.world_size == 1
+    torch.manual_seed(2)
+    vl, al, ent, _ = agent.update()
+    assert all(agent.algo._launched)                               # the bucket all-reduces ran (as the identity)
+    torch.save({"sd": net.state_dict(), "losses": (vl, al, ent)}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_takes_the_exchange_path_and_equals_no_group_bit_for_bit():
+    """A process group of ONE rank runs every exchange step (weight broadcast, hook-launched bucket all-reduces, advantage
+    moments, statistics tail) — each the identity — and must therefore equal the run without a group exactly: what
+    tests/test_gpu_rccl_single.py relies on to exercise RCCL on a one-GPU box."""
+    for p in (ROOT, os.path.join(ROOT, "dcd-isaac_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(G, "ppo.npz"))
+    agent, net = _build(g, [0, 1, 2, 3], None)
+    torch.manual_seed(2)
+    ref_losses = agent.update()[:3]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "r0.pt")
+        mp.spawn(_one_rank_worker, args=(1, 29547, out), nprocs=1, join=True)
+        got = torch.load(out, weights_only=False)
+    assert tuple(got["losses"]) == tuple(ref_losses)
+    for k, v in net.state_dict().items():
+        assert torch.equal(got["sd"][k], v), k
+
+
+def _popart_worker(rank, world, port, out_path):
+    _setup(rank, world, port)
+    from models.popart import PopArt
+    torch.manual_seed(0)
+    pa = PopArt(8, 1)
+    x = torch.randn(64, 1, generator=torch.Generator().manual_seed(3)) * 3 + 1
+    for it in range(3):
+        pa.update(x[rank * 32:(rank + 1) * 32] * (1 + it), group=dist.group.WORLD)
+    torch.save({k: v.clone() for k, v in pa.state_dict().items()}, out_path + str(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_popart_moments_are_job_wide():
+    """PPO under a process group moves PopArt by the moments of the job-wide minibatch (models/popart.py::update(group=)): two
+    ranks x 32 returns end in the SAME state (bit for bit) == one process with the 64 returns (fp32 rounding of the two
+    half-means)."""
+    for p in (ROOT, os.path.join(ROOT, "dcd-isaac_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from models.popart import PopArt
+    torch.manual_seed(0)
+    pa = PopArt(8, 1)
+    x = torch.randn(64, 1, generator=torch.Generator().manual_seed(3)) * 3 + 1
+    for it in range(3):
+        pa.update(x * (1 + it))
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "pa")
+        mp.spawn(_popart_worker, args=(2, 29549, out), nprocs=2, join=True)
+        a, b = torch.load(out + "0"), torch.load(out + "1")
+    for k, v in pa.state_dict().items():
+        assert torch.equal(a[k], b[k]), k
+        np.testing.assert_allclose(a[k].numpy(), v.numpy(), rtol=2e-6, atol=1e-9, err_msg=k)

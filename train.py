@@ -25,7 +25,7 @@ import torch  # noqa: E402
 
 from arguments import parser  # noqa: E402
 from envs.runners import AdversarialRunner  # noqa: E402
-from util import create_parallel_env, make_agent, make_plr_args, safe_checkpoint, save_images, seed  # noqa: E402
+from util import create_parallel_env, load_checkpoint_safe, make_agent, make_plr_args, safe_checkpoint, save_images, seed  # noqa: E402
 from util import distributed as D  # noqa: E402
 from util.filewriter import FileWriter  # noqa: E402
 
@@ -75,35 +75,38 @@ def main():
 
     last_logged_at_restart = -1
     if args.checkpoint and os.path.exists(ckpt):           # --checkpoint only means "resume a preempted job" (train.py:129-134)
-        runner.load_state_dict(torch.load(ckpt, map_location=device, weights_only=False)["runner_state_dict"])
+        runner.load_state_dict(load_checkpoint_safe(ckpt, map_location=device)["runner_state_dict"])
         if writer is not None:
             last_logged_at_restart = writer.latest_tick()  # ticks are 0-indexed updates: rows already in logs.csv are not repeated
+        # only rank 0 reads logs.csv: every rank must skip the same updates (the evaluation below is a collective decision)
+        last_logged_at_restart = int(D.broadcast_ints([last_logged_at_restart], 1, group=pg, device=device)[0]) if world > 1 else last_logged_at_restart
     elif args.xpid_finetune and not os.path.exists(ckpt):  # first iteration of a fine-tuning run (train.py:135-141)
         base = os.path.expandvars(os.path.expanduser(os.path.join(args.log_dir, args.xpid_finetune, f"{args.model_finetune}.tar")))
-        sd = torch.load(base, map_location=device, weights_only=False)["runner_state_dict"]
+        sd = load_checkpoint_safe(base, map_location=device)["runner_state_dict"]    # a foreign file: nothing it names is executed
         runner.agents["agent"].algo.actor_critic.load_state_dict(sd["agent_state_dict"]["agent"])
         runner.agents["agent"].algo.optimizer.load_state_dict(sd["optimizer_state_dict"]["agent"])
     idx_at_start = getattr(runner, args.checkpoint_basis)
     t0 = timeit.default_timer()
     for j in range(runner.num_updates, num_updates):
         stats = D.reduce_stats(runner.run())
-        if runner.num_updates > last_logged_at_restart:    # train.py:165-166
-            if j % args.log_interval == 0 or j == num_updates - 1:
-                test_stats = {}
-                if evaluator is not None and (j % args.test_interval == 0 or j == num_updates - 1):
-                    test_stats = evaluator.evaluate(runner.agents["agent"])
-                if rank == 0:
-                    torch.cuda.synchronize()
-                    now = timeit.default_timer()
-                    n = 1 if j == 0 else args.log_interval                           # train.py:182-184
-                    sps = n * args.num_processes * world * args.num_steps / (now - t0)
-                    t0 = now
-                    row = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else None)
-                           for k, v in stats.items() if not hasattr(v, "__len__")}
-                    row.update(sps=sps)
-                    row.update(test_stats)                                           # sps column before the test stats
-                    writer.log(dict(row))
-                    print(json.dumps(dict(row, update=j)), flush=True)
+        if runner.num_updates <= last_logged_at_restart:   # train.py:165-166: neither logged, checkpointed nor screenshot again
+            continue
+        if j % args.log_interval == 0 or j == num_updates - 1:
+            test_stats = {}
+            if evaluator is not None and (j % args.test_interval == 0 or j == num_updates - 1):
+                test_stats = evaluator.evaluate(runner.agents["agent"])
+            if rank == 0:
+                torch.cuda.synchronize()
+                now = timeit.default_timer()
+                n = 1 if j == 0 else args.log_interval                           # train.py:182-184
+                sps = n * args.num_processes * world * args.num_steps / (now - t0)
+                t0 = now
+                row = {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else None)
+                       for k, v in stats.items() if not hasattr(v, "__len__")}
+                row.update(sps=sps)
+                row.update(test_stats)                                           # sps column before the test stats
+                writer.log(dict(row))
+                print(json.dumps(dict(row, update=j)), flush=True)
         # train.py:190-202: keyed to runner.<checkpoint_basis> (num_updates or student_grad_updates); model.tar at every
         # checkpoint_interval and after the LAST update, numbered copies at every archive_interval
         idx = getattr(runner, args.checkpoint_basis)
