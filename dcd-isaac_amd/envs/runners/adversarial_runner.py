@@ -63,7 +63,13 @@ class AdversarialRunner:
         self.venv = venv
         self.ued_venv = venv if ued_venv is None else ued_venv
         self._pending_updates, self._update_streams, self._deferred_host = [], [], []
-        self._concurrent_updates = (not self.distributed and os.environ.get("DCD_CONCURRENT_PPO", "1") != "0")
+        # DCD_CONCURRENT_PPO=1 (opt-in): the PPO updates of one run() on three streams (_flush_updates).  Refused unless the
+        # process was started with TENSILE_STREAMK_DATA_PARALLEL=1: GEMMs of several streams deadlock otherwise (see there).
+        self._concurrent_updates = not self.distributed and os.environ.get("DCD_CONCURRENT_PPO", "0") == "1"
+        if self._concurrent_updates and os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") != "1":
+            raise ValueError("DCD_CONCURRENT_PPO=1 needs TENSILE_STREAMK_DATA_PARALLEL=1 in the environment the process STARTS with: "
+                             "hipBLASLt's StreamK GEMMs spin on flags between workgroups and deadlock when GEMMs of several streams "
+                             "are in flight (profiles/r03_concurrent_ppo_hang.log); the library reads the variable once")
         self.is_discrete_actions = is_discrete_actions(self.venv)
         self.is_discrete_adversary_env_actions = is_discrete_actions(self.venv, adversary=True)
         self.agents = {"agent": agent, "adversary_agent": adversary_agent, "adversary_env": adversary_env}
@@ -819,12 +825,13 @@ class AdversarialRunner:
         """`agent.update()` (adversarial_runner.py:600-606,810-812) with its losses written into `info`.  The
         protagonist's, the antagonist's and the teacher's updates of one run() touch disjoint networks and storages,
         and nothing between a student's rollout and the end of run() reads a student's new weights (ACCEL's second
-        rollout does: agent_rollout flushes first).  With DCD_CONCURRENT_PPO=1 (default) on one GPU they are therefore
-        queued here and issued together by `_flush_updates`, each from its own host thread on its own stream: one
-        update is a serial chain of small GEMMs and pointwise kernels (the LSTM recurrence), and three independent
-        chains fill the machine better than one (measured: 680 -> 567 ms for the three PAIRED updates).  With several
-        ranks the updates stay in program order: their gradient all-reduces must be issued in the same order on
-        every rank."""
+        rollout does: agent_rollout flushes first).  With DCD_CONCURRENT_PPO=1 on one GPU they are therefore queued here and
+        issued together by `_flush_updates`, each from its own host thread on its own stream: one update is a serial chain of
+        small GEMMs and pointwise kernels (the LSTM recurrence), and three independent chains fill the machine better than one.
+        Round 3: OFF by default — with the library's default (StreamK) GEMMs concurrent streams can deadlock on the GPU; with
+        data-parallel GEMMs (the only safe setting) the three updates take 0.58 s against 0.597 s in program order
+        (profiles/r03_concurrent_ppo_hang.log), a gain that does not pay for a process-wide BLAS override.  With several
+        ranks the updates stay in program order: their gradient all-reduces must be issued in the same order on every rank."""
         self._pending_updates.append((agent, info, discard_grad))
         if not self._concurrent_updates:
             self._flush_updates()
@@ -866,6 +873,12 @@ class AdversarialRunner:
         while len(self._update_streams) < len(jobs):
             self._update_streams.append(torch.cuda.Stream(self.device))
         threads = [threading.Thread(target=work, args=(job, st)) for job, st in zip(jobs, self._update_streams)]
+        # Safe only with data-parallel GEMMs (checked at construction): every fp32 GEMM of this stack (ROCm 7.2 hipBLASLt /
+        # Tensile on gfx950) is a StreamK kernel — workgroups that share an output tile hand partial sums over through flags and
+        # SPIN on them; with GEMMs of several streams in flight each kernel can hold compute units while it waits for workgroups
+        # of its own that cannot be scheduled.  Reproduced: PAIRED at 4096 envs x 8 steps hangs in its first concurrent update,
+        # every time, in the backward passes of two of the three streams; under TENSILE_STREAMK_DATA_PARALLEL=1 (whole tiles per
+        # workgroup, no hand-over; read once per process) 30 such updates run (tools/b4096_bisect.sh).
         for t in threads:
             t.start()
         self._run_deferred_host()                                         # host work of this thread while the GPU trains

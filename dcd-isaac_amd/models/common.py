@@ -41,6 +41,10 @@ def apply_init_(modules, gain=None):
                 nn.init.constant_(m.bias, 0)
 
 
+import os as _os
+MATMUL_TN_MIN_ROWS = int(_os.environ.get("DCD_MATMUL_TN_MIN_ROWS", "65536"))
+
+
 def matmul_tn(a, b):
     """a^T @ b for tall operands ([R, m]^T @ [R, k], R ~ 10^6): the weight-gradient shape of every layer in the PPO
     batch.  rocBLAS runs it as one skinny GEMM with a 10^6-long reduction (1.96 ms for m = 32, k = 256; 5.6 ms for the
@@ -48,7 +52,7 @@ def matmul_tn(a, b):
     partial products (split-K) the same contraction takes 0.25 / 0.28 ms (tools/splitk_probe.py).  Same fp32 products,
     partial sums added in a different order."""
     R = a.size(0)
-    if not a.is_cuda or R < 65536:
+    if not a.is_cuda or R < MATMUL_TN_MIN_ROWS:
         return a.t() @ b
     S = 256
     while S > 1 and (R % S or R // S < 256):

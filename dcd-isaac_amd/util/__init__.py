@@ -62,23 +62,63 @@ def safe_checkpoint(state_dict, path, index=None, archive_interval=None):
         shutil.copy(path, f"{filename}_{index}{ext}")
 
 
+def _checkpoint_allow_list():
+    """(module, name) pairs a runner checkpoint may name: torch's own weights-only list (tensor rebuilders, storages, dtypes,
+    OrderedDict ...) + the containers, numpy types and the four host-side classes adversarial_runner.py:203-216 pickles."""
+    allow = set()
+    try:
+        from torch._weights_only_unpickler import _get_allowed_globals
+        for full in _get_allowed_globals():
+            mod, _, name = full.rpartition(".")
+            allow.add((mod, name))
+    except Exception:                                            # noqa: BLE001  (private helper: fall back to the essentials)
+        allow |= {("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"), ("collections", "OrderedDict"),
+                  ("torch", "FloatStorage"), ("torch", "LongStorage"), ("torch", "IntStorage"), ("torch", "ByteStorage"),
+                  ("torch", "DoubleStorage"), ("torch", "BoolStorage"), ("torch", "HalfStorage"), ("torch.storage", "UntypedStorage")}
+    allow |= {("collections", n) for n in ("deque", "defaultdict", "OrderedDict")}
+    for mod in ("builtins", "__builtin__"):                       # protocol <= 2 pickles name the Python-2 module
+        allow |= {(mod, n) for n in ("set", "frozenset", "float", "int", "list", "dict", "tuple", "str", "bool", "bytes", "complex", "slice",
+                                     "range", "object", "bytearray")}
+    allow |= {("copy_reg", "_reconstructor"), ("copyreg", "_reconstructor")}     # object.__new__(cls) of an allow-listed cls
+    for mod in ("numpy", "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric"):
+        allow |= {(mod, n) for n in ("ndarray", "dtype", "_reconstruct", "scalar", "_frombuffer", "float64", "float32", "int64", "int32",
+                                     "int16", "int8", "uint64", "uint32", "uint16", "uint8", "bool_", "bool")}
+    allow |= {("numpy.dtypes", n) for n in ("Float64DType", "Float32DType", "Int64DType", "Int32DType", "Int16DType", "Int8DType", "UInt64DType",
+                                             "UInt32DType", "UInt16DType", "UInt8DType", "BoolDType", "ObjectDType", "BytesDType", "StrDType")}
+    allow |= {("level_replay.level_sampler", "LevelSampler"), ("level_replay.level_store", "LevelStore"),
+              ("level_replay.sharded", "ShardedLevelSampler"), ("level_replay.sharded", "ShardedLevelStore"),
+              ("envs.spaces", "Box"), ("envs.spaces", "Discrete"), ("envs.spaces", "Dict")}
+    return allow
+
+
+class _AllowListPickle:
+    """A `pickle_module` for torch.load whose Unpickler resolves ONLY allow-listed globals (the restricted-unpickler recipe of the
+    pickle documentation).  torch.load(weights_only=True) cannot be used: its unpickler refuses to rebuild a non-empty
+    collections.deque (`agent_returns`, adversarial_runner.py:206), which every runner checkpoint holds."""
+    import pickle as _pickle
+    __name__ = "dcd_allow_list_pickle"
+    load, loads, dump, dumps = _pickle.load, _pickle.loads, _pickle.dump, _pickle.dumps
+    Pickler, UnpicklingError, PickleError = _pickle.Pickler, _pickle.UnpicklingError, _pickle.PickleError
+    HIGHEST_PROTOCOL, DEFAULT_PROTOCOL = _pickle.HIGHEST_PROTOCOL, _pickle.DEFAULT_PROTOCOL
+    _allowed = None
+
+    class Unpickler(_pickle.Unpickler):
+        def find_class(self, module, name):
+            if _AllowListPickle._allowed is None:
+                _AllowListPickle._allowed = _checkpoint_allow_list()
+            if (module, name) not in _AllowListPickle._allowed:
+                import pickle
+                raise pickle.UnpicklingError(f"checkpoint names {module}.{name}, which is not on the allow-list of "
+                                             f"util.load_checkpoint_safe: refused (nothing from the file was executed)")
+            return super().find_class(module, name)
+
+
 def load_checkpoint_safe(path, map_location=None):
-    """torch.load of a `model.tar` without running anything the file names: `weights_only=True`, with an allow-list of exactly
-    the non-tensor types a runner checkpoint holds (adversarial_runner.py:203-216 pickles the LevelSampler / LevelStore objects
-    and their numpy arrays next to the state dicts; the module paths are the reference's, so its checkpoints name the same
-    classes).  A file that names anything else is refused with torch's UnpicklingError — it is not executed."""
-    import collections
-    import numpy as np
-    from level_replay.level_sampler import LevelSampler
-    from level_replay.level_store import LevelStore
-    from level_replay.sharded import ShardedLevelSampler, ShardedLevelStore
-    from envs import spaces
-    allow = [LevelSampler, LevelStore, ShardedLevelSampler, ShardedLevelStore, spaces.Box, spaces.Discrete, spaces.Dict, collections.defaultdict, collections.OrderedDict,
-             collections.deque, set, frozenset, float, int, list, dict, tuple, str, bool, np.ndarray, np.dtype, np._core.multiarray._reconstruct, np._core.multiarray.scalar]
-    allow += [np.float64, np.float32, np.int64, np.int32, np.int16, np.int8, np.uint64, np.uint32, np.uint16, np.uint8, np.bool_]
-    allow += sorted({type(np.dtype(t)) for t in ("f8", "f4", "i8", "i4", "i2", "i1", "u8", "u4", "u2", "u1", "?", "O", "S1", "U1")}, key=repr)
-    with torch.serialization.safe_globals(allow):
-        return torch.load(path, map_location=map_location, weights_only=True)
+    """torch.load of a `model.tar` that executes nothing the file names beyond an allow-list: tensors, containers, numpy
+    arrays / scalars and the host-side classes a runner checkpoint pickles next to the state dicts (adversarial_runner.py:
+    203-216: LevelSampler, LevelStore — the module paths are the reference's, so its checkpoints name the same classes — and
+    the observation / action spaces they hold).  A file that names anything else raises pickle.UnpicklingError."""
+    return torch.load(path, map_location=map_location, weights_only=False, pickle_module=_AllowListPickle)
 
 
 def save_images(images, path=None, normalize=False, channels_first=False, nrow=8, padding=2):

@@ -246,52 +246,6 @@ def test_graph_replayed_rollouts_equal_eager_rollouts(monkeypatch):
     assert not torch.equal(results["1"][2]["actions"], results["1"][3]["actions"])
 
 
-def test_concurrent_ppo_updates_match_in_order_updates(monkeypatch):
-    """The three PPO updates of a PAIRED run() are independent and are issued together from three host threads on three
-    streams (DCD_CONCURRENT_PPO=1, default); =0 issues them in the reference's program order.  One PPO update is run-to-run
-    bit-deterministic on this path (tools/ppo_determinism.py: max |dw| = 0 over repeats, student and teacher), and the
-    minibatch permutations are drawn in program order before the threads start, so the two settings must agree EXACTLY:
-    same seeds -> same losses, same gradient norms, same weights after two updates."""
-    out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("DCD_CONCURRENT_PPO", mode)
-        args = make_args(ued_algo="paired", ppo_epoch=2, adv_ppo_epoch=2, num_mini_batch=2)
-        runner, venv = build(args)
-        assert runner._concurrent_updates == (mode == "1")
-        stats = [runner.run() for _ in range(2)]
-        assert not runner._pending_updates
-        out[mode] = (stats, {n: {k: v.clone() for k, v in a.algo.actor_critic.state_dict().items()} for n, a in runner.agents.items()},
-                     runner.agents["agent"].storage.actions.clone())
-        venv.close()
-    (s0, w0, a0), (s1, w1, a1) = out["0"], out["1"]
-    assert torch.equal(a0, a1)
-    for j in range(2):
-        for k in ("mean_env_return", "total_episodes", "agent_value_loss", "adversary_value_loss", "adversary_env_value_loss",
-                  "agent_pg_loss", "adversary_env_pg_loss", "agent_grad_norm", "adversary_grad_norm", "adversary_env_grad_norm"):
-            assert np.isfinite(s1[j][k]) and s1[j][k] == s0[j][k], (j, k, s0[j][k], s1[j][k])
-    for n in w0:
-        for k in w0[n]:
-            assert torch.equal(w1[n][k], w0[n][k]), f"{n}.{k}"
-
-
-def test_same_seed_reproduces_a_concurrent_run(monkeypatch):
-    """Two runs from the same --seed with the concurrent updates on: identical stats and weights (the minibatch
-    permutations used to be drawn inside the worker threads from the shared global generator)."""
-    monkeypatch.setenv("DCD_CONCURRENT_PPO", "1")
-    res = []
-    for _ in range(2):
-        args = make_args(ued_algo="paired", ppo_epoch=3, adv_ppo_epoch=3, num_mini_batch=4)
-        runner, venv = build(args)
-        stats = [runner.run() for _ in range(2)]
-        res.append((stats[-1], {n: {k: v.clone() for k, v in a.algo.actor_critic.state_dict().items()} for n, a in runner.agents.items()}))
-        venv.close()
-    for k in ("agent_value_loss", "adversary_value_loss", "adversary_env_value_loss", "mean_env_return"):
-        assert res[0][0][k] == res[1][0][k], k
-    for n in res[0][1]:
-        for k in res[0][1][n]:
-            assert torch.equal(res[0][1][n][k], res[1][1][n][k]), f"{n}.{k}"
-
-
 def _storage_tensors(st):
     out = {k: v for k, v in vars(st).items() if isinstance(v, torch.Tensor)}
     for name in ("obs", "truncated_obs"):
