@@ -57,6 +57,7 @@ class AdversarialRunner:
         # a group of ONE rank takes the same code path as a group of eight — every collective runs (as the identity): that is how
         # the RCCL path is exercised on a one-GPU box (tests/test_gpu_rccl_single.py)
         self.distributed = process_group is not None
+        self.prefetch_draws = os.environ.get("DCD_PREFETCH_DRAWS", "1") != "0"
         if process_group is not None:
             import torch.distributed as dist
             self.world_size = dist.get_world_size(process_group)
@@ -810,9 +811,13 @@ class AdversarialRunner:
                     signed=False, positive_only=False, clipped=clipped, batched=True)
             if level_sampler and update_level_sampler:
                 level_sampler.update_with_rollouts(st)
-            self._submit_update(agent, rollout_info, discard_grad=discard_grad)
-            if level_sampler and update_level_sampler:
                 level_sampler.after_update()                              # sampler bookkeeping: independent of the PPO result
+                # the sampler now is what the NEXT update's replay decision and first draws will see: they are computed on a
+                # host thread (C loop, outside the GIL) underneath this update's PPO kernels and used if nothing moves in between
+                if (self.prefetch_draws and self.is_training and len(self.all_level_samplers) == 1 and not self.use_editor
+                        and level_sampler is self._default_level_sampler):
+                    level_sampler.prefetch_next_update(args.num_processes)
+            self._submit_update(agent, rollout_info, discard_grad=discard_grad)
             if args.log_action_complexity:
                 if self._concurrent_updates:              # host-side LZ76 pass (5 ms per student): runs under the PPO updates
                     self._deferred_host.append((rollout_info, st, st.action_complexity_inputs()))

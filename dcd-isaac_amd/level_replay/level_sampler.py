@@ -390,22 +390,100 @@ class LevelSampler:
             self.seed_staleness = self.seed_staleness + 1
             self.seed_staleness[selected_idx] = 0
 
+    # ---- speculative prefetch of the next update's first draws ------------------------------------------------------------
+    # What an update asks of the sampler first — sample_replay_decision(), then, on a replay update, one level per actor
+    # (adversarial_runner.py:616-622,463) — depends only on the sampler's state after the previous update's after_update() and
+    # on the position of the np.random stream.  `prefetch_next_update(n)` computes both on a background host thread from a
+    # SHADOW of that state (copies of the arrays a draw touches, a private RandomState started at the global stream's
+    # position) while the GPU runs the PPO update; the sequential draw loop is C code outside the GIL.  The next
+    # sample_replay_decision() / sample_replay_levels(n) consume the result ONLY IF nothing has moved in between — same
+    # global np.random state, same scores / staleness / seeds — and then install exactly what the sequential calls would have
+    # left behind (staleness, versions, the global stream advanced past the same doubles).  Otherwise the speculation is
+    # dropped and the calls run as always: bit-identical either way (tests/test_sampler_prefetch.py).
+    @property
+    def _rng(self):
+        return self.__dict__.get("_shadow_rng") or np.random
+
+    _PREFETCH_ARRAYS = ("seed_scores", "seed_staleness", "unseen_seed_weights", "seeds")
+
+    def prefetch_next_update(self, n_initial):
+        import copy
+        import threading
+        self._drop_prefetch()
+        rng_transforms = self.score_transform == "max" or (self.staleness_coef > 0 and self.staleness_transform == "max")
+        if n_initial <= 1 or rng_transforms or not self._has_working_seed_buffer:
+            return False
+        shadow = copy.copy(self)
+        for k in self._PREFETCH_ARRAYS:
+            setattr(shadow, k, np.array(getattr(self, k), copy=True))
+        shadow.__dict__.pop("_prefetch", None)
+        state0 = np.random.get_state()
+        shadow._shadow_rng = np.random.RandomState()
+        shadow._shadow_rng.set_state(state0)
+        job = {"n": int(n_initial), "rng0": state0, "snap": {k: np.array(getattr(self, k), copy=True) for k in self._PREFETCH_ARRAYS},
+               "filled": self._proportion_filled, "shadow": shadow, "stage": 0}
+
+        def work():
+            try:
+                job["decision"] = shadow._sample_replay_decision_now()
+                job["rng1"] = shadow._shadow_rng.get_state()
+                if job["decision"]:
+                    job["seeds_out"] = shadow._sample_replay_levels_now(job["n"], True)
+                    job["rng2"] = shadow._shadow_rng.get_state()
+            except BaseException as exc:                          # noqa: BLE001  (a failed speculation is simply not used)
+                job["error"] = exc
+        job["thread"] = threading.Thread(target=work, daemon=True)
+        job["thread"].start()
+        self._prefetch = job
+        return True
+
+    def _drop_prefetch(self):
+        job = self.__dict__.pop("_prefetch", None)
+        if job is not None:
+            job["thread"].join()
+
+    @staticmethod
+    def _same_rng(a, b):
+        return a[0] == b[0] and a[2:] == b[2:] and np.array_equal(a[1], b[1])
+
+    def _prefetch_valid(self, job, rng_key):
+        """The speculation started from exactly the state the sequential call sees now."""
+        job["thread"].join()
+        if "error" in job or not self._same_rng(np.random.get_state(), job[rng_key]) or self._proportion_filled != job["filled"]:
+            return False
+        return all(np.array_equal(getattr(self, k), job["snap"][k]) for k in self._PREFETCH_ARRAYS)
+
     def sample_replay_decision(self):
+        job = self.__dict__.get("_prefetch")
+        if job is not None and job["stage"] == 0:
+            if self._prefetch_valid(job, "rng0"):
+                np.random.set_state(job["rng1"])                  # the stream past the (at most one) double the decision drew
+                job["stage"] = 1
+                if not job["decision"]:
+                    self.__dict__.pop("_prefetch", None)
+                self.prefetch_hits = getattr(self, "prefetch_hits", 0) + 1
+                return job["decision"]
+            self._drop_prefetch()
+        elif job is not None:
+            self._drop_prefetch()
+        return self._sample_replay_decision_now()
+
+    def _sample_replay_decision_now(self):
         if self.sample_full_distribution:
             filled = self._proportion_filled
             if self.seed_buffer_size <= 0:
                 return False
             if self.replay_schedule == "fixed":
-                return bool(filled >= self.rho and np.random.rand() < self.replay_prob)
-            return bool(filled >= self.rho and np.random.rand() < min(filled, self.replay_prob))
+                return bool(filled >= self.rho and self._rng.rand() < self.replay_prob)
+            return bool(filled >= self.rho and self._rng.rand() < min(filled, self.replay_prob))
         if self.replay_schedule == "fixed":
             seen = self._proportion_filled
             if seen >= self.rho:
-                if np.random.rand() < self.replay_prob or not seen < 1.0:
+                if self._rng.rand() < self.replay_prob or not seen < 1.0:
                     return True
             return False
         seen = self._proportion_filled
-        return bool(seen >= self.rho and np.random.rand() < seen)
+        return bool(seen >= self.rho and self._rng.rand() < seen)
 
     def observe_external_unseen_sample(self, seeds, solvable=None):
         for i, seed in enumerate(seeds):
@@ -437,13 +515,31 @@ class LevelSampler:
 
     def _sample_replay_level(self, update_staleness=True):
         w = self._replay_distribution()
-        seed_idx = np.random.choice(range(len(self.seeds)), 1, p=w)[0]
+        seed_idx = self._rng.choice(range(len(self.seeds)), 1, p=w)[0]
         seed = self.seeds[seed_idx]
         if update_staleness:
             self._update_staleness(seed_idx)
         return int(seed)
 
     def sample_replay_levels(self, n, update_staleness=True):
+        """`_sample_replay_levels_now`, or its prefetched result when one is pending and still valid (see above)."""
+        job = self.__dict__.get("_prefetch")
+        if job is not None:
+            ok = (job["stage"] == 1 and job.get("decision") and n == job["n"] and update_staleness and self._prefetch_valid(job, "rng1"))
+            self.__dict__.pop("_prefetch", None)
+            if ok:
+                shadow = job["shadow"]
+                np.random.set_state(job["rng2"])
+                self.seed_staleness = shadow.seed_staleness
+                self._state_version = getattr(shadow, "_state_version", 0)
+                if "_score_half" in shadow.__dict__:
+                    self._score_half = shadow._score_half
+                self.prefetch_hits = getattr(self, "prefetch_hits", 0) + 1
+                return job["seeds_out"]
+            job["thread"].join()
+        return self._sample_replay_levels_now(n, update_staleness)
+
+    def _sample_replay_levels_now(self, n, update_staleness=True):
         """n sequential draws of sample_replay_level() (the runner's per-env loop, adversarial_runner.py:463) — same
         draws, same RNG consumption, same staleness bookkeeping as n separate calls, without recomputing what cannot
         change between them: seed scores are fixed during a batch of draws, so the score half of `sample_weights`
@@ -477,7 +573,7 @@ class LevelSampler:
         w_scores = (1 - c) * ws if c > 0 else ws                     # constant across the batch of draws
         # 'power' with temperature 1 and eps 0 (staleness_coef > 0): (clip(s, 0) + 0) ** 1.0 is s itself, bit for bit
         plain_staleness = self.staleness_transform == "power" and self.staleness_temperature == 1.0
-        uniforms = np.random.random_sample(n)                        # the n doubles n calls of choice(..., 1, p=w) would draw
+        uniforms = self._rng.random_sample(n)                        # the n doubles n calls of choice(..., 1, p=w) would draw
         out, k = [], 0
         if c > 0 and plain_staleness and _native_draws_available():
             # the same loop in C (dcd_sampler_draws, csrc/host_utils.cpp): same IEEE operations in the same order
@@ -517,7 +613,7 @@ class LevelSampler:
                 w = w / total
             cdf = w.cumsum()
             if not (abs(cdf[-1] - 1.0) <= 1e-8) or w.min() < 0:     # let numpy raise exactly as the sequential path would
-                seed_idx = np.random.choice(range(N), 1, p=w)[0]
+                seed_idx = self._rng.choice(range(N), 1, p=w)[0]
             else:
                 cdf /= cdf[-1]
                 seed_idx = int(cdf.searchsorted(uniforms[j:j + 1], side="right")[0])
@@ -624,4 +720,6 @@ class LevelSampler:
     def __getstate__(self):                    # checkpoints pickle the sampler (adversarial_runner.py:214)
         d = dict(self.__dict__)
         d["_scorer"] = None
+        d.pop("_prefetch", None)
+        d.pop("_shadow_rng", None)
         return d

@@ -92,6 +92,37 @@ def test_robust_plr_runs_and_fills_buffer():
     venv.close()
 
 
+def test_prefetched_replay_draws_equal_the_sequential_order(monkeypatch):
+    """DCD_PREFETCH_DRAWS (default on): the next update's replay decision and first draws are computed on a host thread under
+    the PPO kernels of the current one (LevelSampler.prefetch_next_update) — every decision, every env's seeds, the sampler's
+    state and the students' weights must equal the run that draws in program order (=0)."""
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DCD_PREFETCH_DRAWS", mode)
+        args = make_args(ued_algo="domain_randomization", use_plr=True, use_reset_random_dr=True, no_exploratory_grad_updates=True,
+                         level_replay_strategy="positive_value_loss", level_replay_score_transform="rank", level_replay_prob=0.7,
+                         level_replay_rho=0.2, level_replay_seed_buffer_size=100, staleness_coef=0.3, log_plr_buffer_stats=True,
+                         recurrent_adversary_env=False, num_steps=64, env_name="MultiGrid-MiniGoalLastAdversarial-v0")
+        runner, venv = build(args)
+        np.random.seed(4)
+        log = []
+        for j in range(10):
+            s = runner.run()
+            log.append((bool(runner.sampled_level_info["level_replay"]), list(runner.current_level_seeds), s["agent_plr_passable_mass"],
+                        s["agent_value_loss"]))
+        sampler = runner.level_samplers["agent"]
+        out[mode] = (log, sampler.seed_staleness.copy(), sampler.seed_scores.copy(), np.random.get_state()[1].copy(),
+                     torch.cat([p.detach().flatten() for p in runner.agents["agent"].algo.actor_critic.parameters()]).clone(),
+                     getattr(sampler, "prefetch_hits", 0))
+        venv.close()
+    a, b = out["0"], out["1"]
+    assert a[5] == 0 and b[5] >= 8                                  # speculation off / consumed
+    assert sum(x[0] for x in a[0]) >= 2
+    for x, y in zip(a[0], b[0]):
+        assert x[0] == y[0] and x[1] == y[1] and x[3] == y[3] and (x[2] == y[2] or (x[2] != x[2] and y[2] != y[2]))
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and torch.equal(a[4], b[4])
+
+
 def test_accel_edits_levels():
     args = make_args(ued_algo="domain_randomization", use_plr=True, use_reset_random_dr=True, no_exploratory_grad_updates=True,
                      use_editor=True, level_editor_prob=1.0, num_edits=5, base_levels="easy",

@@ -53,7 +53,7 @@ def _records(u, g0, seeds):
     return np.array(out, dtype=REC)
 
 
-def _drive(sampler, store, g0, n_local, update_records):
+def _drive(sampler, store, g0, n_local, update_records, prefetch=False):
     """The runner's PLR call sequence (adversarial_runner.py:676-896) over `n_local` envs starting at global env g0."""
     log = []
     for u in range(UPDATES):
@@ -75,6 +75,8 @@ def _drive(sampler, store, g0, n_local, update_records):
                         k += 1
         update_records(_records(u, g0, seeds))
         sampler.after_update()
+        if prefetch:                                                 # as the runner: the next update's first draws, speculatively
+            sampler.prefetch_next_update(n_local)
         store.reconcile_seeds(set(int(x) for x in sampler.seeds if x >= 0))
         log.append((bool(replay), [int(s) for s in seeds], float(sampler.solvable_mass), float(sampler.max_score)))
     return log
@@ -93,7 +95,9 @@ def _worker(rank, world, port, out_dir):
     np.random.seed(7 if rank == 0 else 12345)                        # only rank 0's stream may matter
     sampler = ShardedLevelSampler(_plr_args(B_LOCAL), group=dist.group.WORLD)
     store = ShardedLevelStore(group=dist.group.WORLD)
-    log = _drive(sampler, store, rank * B_LOCAL, B_LOCAL, lambda recs: sampler.update_with_records(recs, device="cpu"))
+    log = _drive(sampler, store, rank * B_LOCAL, B_LOCAL, lambda recs: sampler.update_with_records(recs, device="cpu"), prefetch=True)
+    if rank == 0:
+        assert getattr(sampler.sampler, "prefetch_hits", 0) >= UPDATES - 2           # the speculation was consumed, not dropped
     with open(os.path.join(out_dir, f"r{rank}.pkl"), "wb") as f:
         pickle.dump({"log": log, "state": _state(sampler.sampler) if rank == 0 else None,
                      "store": (store.seed2level, store.seed2parent, store.next_seed)}, f)

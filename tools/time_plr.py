@@ -19,11 +19,17 @@ venv, ued = create_parallel_env(args, device=dev)
 agent = make_agent("agent", venv, args, dev); teacher = make_agent("adversary_env", venv, args, dev); teacher.random()
 runner = AdversarialRunner(args=args, venv=venv, agent=agent, ued_venv=ued, adversary_env=teacher, train=True,
                            plr_args=make_plr_args(args, venv.observation_space, venv.action_space), device=dev)
+SIM = int(os.environ.get("SIM_WORLD", "1"))       # rank 0 of an N-rank job draws N x as many levels: time the host side as if N ranks asked
+if SIM > 1:
+    ls = runner.level_samplers["agent"]
+    draw, pre = ls.sample_replay_levels, ls.prefetch_next_update
+    ls.sample_replay_levels = lambda n, **k: draw(n * SIM, **k)[:n]
+    ls.prefetch_next_update = lambda n: pre(n * SIM)
 import cProfile, pstats
 prof_replay = prof_explore = False
 for j in range(12):
     torch.cuda.synchronize(); t = time.perf_counter()
-    pr = cProfile.Profile() if j >= 4 else None
+    pr = cProfile.Profile() if (j >= 4 and not os.environ.get("NO_PROFILE")) else None
     if pr: pr.enable()
     stats = runner.run()
     torch.cuda.synchronize(); dt = time.perf_counter() - t
@@ -35,4 +41,4 @@ for j in range(12):
             pstats.Stats(pr).sort_stats("tottime").print_stats(14)
             prof_replay, prof_explore = prof_replay or rep, prof_explore or not rep
     print(json.dumps({"update": j, "replay": bool(runner.sampled_level_info["level_replay"]), "seconds": round(dt, 3),
-                      "env_steps_per_s": round(B * 256 / dt), "buffer": int(runner.level_samplers["agent"].working_seed_buffer_size)}), flush=True)
+                      "env_steps_per_s": round(B * 256 / dt), "buffer": int(runner.level_samplers["agent"].working_seed_buffer_size), "prefetch_hits": getattr(runner.level_samplers["agent"], "prefetch_hits", 0), "sim_world": SIM}), flush=True)
