@@ -58,6 +58,7 @@ class AdversarialRunner:
         # the RCCL path is exercised on a one-GPU box (tests/test_gpu_rccl_single.py)
         self.distributed = process_group is not None
         self.prefetch_draws = os.environ.get("DCD_PREFETCH_DRAWS", "1") != "0"
+        self.prefetch_stream_factor = int(os.environ.get("DCD_PREFETCH_STREAM", "3"))
         if process_group is not None:
             import torch.distributed as dist
             self.world_size = dist.get_world_size(process_group)
@@ -816,7 +817,9 @@ class AdversarialRunner:
                 # host thread (C loop, outside the GIL) underneath this update's PPO kernels and used if nothing moves in between
                 if (self.prefetch_draws and self.is_training and len(self.all_level_samplers) == 1 and not self.use_editor
                         and level_sampler is self._default_level_sampler):
-                    level_sampler.prefetch_next_update(args.num_processes)
+                    # + the stream of per-episode re-sampling draws a replay rollout will ask for step by step (~1.5 per env
+                    # at 250-step episodes; what is not speculated is drawn in program order)
+                    level_sampler.prefetch_next_update(args.num_processes, stream_extra=self.prefetch_stream_factor * args.num_processes)
             self._submit_update(agent, rollout_info, discard_grad=discard_grad)
             if args.log_action_complexity:
                 if self._concurrent_updates:              # host-side LZ76 pass (5 ms per student): runs under the PPO updates

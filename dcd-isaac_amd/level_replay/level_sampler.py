@@ -79,6 +79,30 @@ def _native_draws_available():
     return _NATIVE_DRAWS
 
 
+class _RecordingRng:
+    """A RandomState that remembers the doubles `random_sample` handed out (the speculated draws' uniforms); any other way of
+    consuming the stream marks the recording unsafe."""
+
+    def __init__(self, rs):
+        self.rs, self.doubles, self.unsafe = rs, [], False
+
+    def random_sample(self, n):
+        d = self.rs.random_sample(n)
+        self.doubles.append(np.array(d, copy=True))
+        return d
+
+    def rand(self, *a):
+        self.unsafe = True
+        return self.rs.rand(*a)
+
+    def choice(self, *a, **k):
+        self.unsafe = True
+        return self.rs.choice(*a, **k)
+
+    def get_state(self):
+        return self.rs.get_state()
+
+
 class LevelSampler:
     def __init__(self, seeds, obs_space, action_space, num_actors=1, strategy="random", max_score_coef=0.0,
                  replay_schedule="fixed", score_transform="power", temperature=1.0, eps=0.05, rho=1.0,
@@ -265,6 +289,7 @@ class LevelSampler:
     def update_with_rollouts(self, rollouts):
         """GPU segmentation + scoring of `rollouts` (a RolloutStorage on a HIP device), then the
         sequential host update (reference :149-183, :486-578)."""
+        self._settle_if_streaming()
         if self.strategy in ("random", "off") or not self._has_working_seed_buffer:
             return
         if self.strategy not in _GPU_STRATEGY:
@@ -314,6 +339,7 @@ class LevelSampler:
         numpy) is required for grounded_* strategies; actor_offset shifts local actor indices of a
         remote rank into the global actor space.  The record fields are unpacked to Python lists once: at
         B = 4096 a rollout yields ~8k records and per-record numpy field access dominated the update."""
+        self._settle_if_streaming()
         grounded = self.grounded_values is not None
         positive = self.strategy == "grounded_positive_value_loss"
         recs = np.asarray(recs)
@@ -360,6 +386,7 @@ class LevelSampler:
         """Flush partial scores (policy changed, logits stale) — reference :580-599.  The reference scans the whole
         [num_actors, N] matrix in row-major order; the same entries are visited here, in the same order, from the
         set of pairs that received a partial update."""
+        self._settle_if_streaming()
         if not self._has_working_seed_buffer:
             return
         dirty = getattr(self, "_partial_dirty", None)
@@ -406,7 +433,12 @@ class LevelSampler:
 
     _PREFETCH_ARRAYS = ("seed_scores", "seed_staleness", "unseen_seed_weights", "seeds")
 
-    def prefetch_next_update(self, n_initial):
+    def prefetch_next_update(self, n_initial, stream_extra=None):
+        """stream_extra: how many draws BEYOND the first n_initial the thread keeps producing afterwards (the per-episode
+        re-sampling of the replay rollout, adversarial_runner.py:551-558, asks for them a few at a time): the draws are one
+        sequential stream however the requests cut it, so they are speculated in chunks of STREAM_CHUNK with a staleness
+        snapshot per chunk; a request pops its draws and burns the same doubles from the global stream (which doubles as the
+        validity check); `_settle` installs the staleness after exactly the draws that were popped."""
         import copy
         import threading
         self._drop_prefetch()
@@ -421,7 +453,9 @@ class LevelSampler:
         shadow._shadow_rng = np.random.RandomState()
         shadow._shadow_rng.set_state(state0)
         job = {"n": int(n_initial), "rng0": state0, "snap": {k: np.array(getattr(self, k), copy=True) for k in self._PREFETCH_ARRAYS},
-               "filled": self._proportion_filled, "shadow": shadow, "stage": 0}
+               "filled": self._proportion_filled, "shadow": shadow, "stage": 0, "initial_done": threading.Event(),
+               "cv": threading.Condition(), "finished": False, "stop": False, "extra": int(stream_extra or 0),
+               "q_seeds": [], "q_uniforms": [], "snaps": [], "produced": 0, "used": 0}
 
         def work():
             try:
@@ -430,17 +464,103 @@ class LevelSampler:
                 if job["decision"]:
                     job["seeds_out"] = shadow._sample_replay_levels_now(job["n"], True)
                     job["rng2"] = shadow._shadow_rng.get_state()
+                    job["initial_done"].set()
+                    self._stream_ahead(job, shadow)
             except BaseException as exc:                          # noqa: BLE001  (a failed speculation is simply not used)
                 job["error"] = exc
+            finally:
+                job["initial_done"].set()
+                with job["cv"]:
+                    job["finished"] = True
+                    job["cv"].notify_all()
         job["thread"] = threading.Thread(target=work, daemon=True)
         job["thread"].start()
         self._prefetch = job
         return True
 
-    def _drop_prefetch(self):
+    STREAM_CHUNK = 512
+
+    def _stream_ahead(self, job, shadow):
+        """Thread side: draws n_initial+1, n_initial+2, ... on the shadow, in chunks, until `extra` are out or the stream is stopped."""
+        rec = _RecordingRng(shadow._shadow_rng)
+        shadow._shadow_rng = rec
+        job["snaps"].append(shadow.seed_staleness.copy())          # staleness after the initial draws = before chunk 0
+        while job["produced"] < job["extra"] and not job["stop"]:
+            c = min(self.STREAM_CHUNK, job["extra"] - job["produced"])
+            rec.doubles, rec.unsafe = [], False
+            seeds = shadow._sample_replay_levels_now(c, True)
+            if rec.unsafe or sum(len(d) for d in rec.doubles) != c:   # a draw went through numpy's own choice(): not replayable
+                break
+            with job["cv"]:
+                job["q_seeds"].extend(seeds)
+                job["q_uniforms"].append(np.concatenate(rec.doubles))
+                job["snaps"].append(shadow.seed_staleness.copy())
+                job["produced"] += c
+                job["cv"].notify_all()
+
+    def _stream_pop(self, job, n):
+        """Consumer side: the next n draws of the stream, or None when it cannot serve them (the caller then settles and draws
+        in program order).  The global np.random stream is advanced by the n doubles these draws consumed — and must hold
+        exactly those doubles, else something overtook the speculation."""
+        if n == 0:
+            return []
+        with job["cv"]:
+            while job["produced"] < job["used"] + n and not job["finished"]:
+                job["cv"].wait()
+            if job["produced"] < job["used"] + n:
+                return None
+            lo = job["used"]
+            seeds = job["q_seeds"][lo:lo + n]
+        state = np.random.get_state()
+        burned = np.random.random_sample(n)
+        have = self._stream_uniforms(job, lo, n)
+        if not np.array_equal(burned, have):
+            np.random.set_state(state)                            # untouched: the sequential path draws these doubles itself
+            return None
+        job["used"] = lo + n
+        return seeds
+
+    def _settle_if_streaming(self):
+        """State-changing entry points end an OPEN stream first (its staleness is installed on settling); a speculation
+        that has not been consumed yet (stage 0 / 1) is left to its own validity check."""
+        job = self.__dict__.get("_prefetch")
+        if job is not None and job["stage"] == 2:
+            self._settle()
+
+    def _stream_uniforms(self, job, lo, n):
+        """Doubles lo .. lo+n of the stream (chunk k holds doubles [k * STREAM_CHUNK, (k + 1) * STREAM_CHUNK))."""
+        C, parts = self.STREAM_CHUNK, []
+        while n > 0:
+            k, o = divmod(lo, C)
+            take = min(n, C - o)
+            parts.append(job["q_uniforms"][k][o:o + take])
+            lo, n = lo + take, n - take
+        return parts[0] if len(parts) == 1 else np.concatenate(parts)
+
+    def _settle(self):
+        """Ends any speculation: joins the thread and, if a stream served per-step draws, installs the staleness after exactly
+        those draws (snapshot at the chunk boundary below + a replay of the remainder with the recorded doubles)."""
         job = self.__dict__.pop("_prefetch", None)
-        if job is not None:
-            job["thread"].join()
+        if job is None:
+            return
+        job["stop"] = True
+        job["thread"].join()
+        used = job["used"]
+        if job["stage"] == 2 and used:
+            C = self.STREAM_CHUNK
+            a, r = divmod(used, C)
+            tmp = job["shadow"]
+            tmp.seed_staleness = job["snaps"][a].copy()
+            if r:
+                uni = self._stream_uniforms(job, a * C, r)
+                tmp._shadow_rng = None
+                again = tmp._sample_replay_levels_now(r, True, uniforms=uni)
+                assert again == job["q_seeds"][a * C:a * C + r], "replay of the speculated draws diverged"
+            self.seed_staleness = tmp.seed_staleness
+            self._state_version = getattr(self, "_state_version", 0) + 1
+
+    def _drop_prefetch(self):
+        self._settle()
 
     @staticmethod
     def _same_rng(a, b):
@@ -448,7 +568,7 @@ class LevelSampler:
 
     def _prefetch_valid(self, job, rng_key):
         """The speculation started from exactly the state the sequential call sees now."""
-        job["thread"].join()
+        job["initial_done"].wait()
         if "error" in job or not self._same_rng(np.random.get_state(), job[rng_key]) or self._proportion_filled != job["filled"]:
             return False
         return all(np.array_equal(getattr(self, k), job["snap"][k]) for k in self._PREFETCH_ARRAYS)
@@ -460,7 +580,7 @@ class LevelSampler:
                 np.random.set_state(job["rng1"])                  # the stream past the (at most one) double the decision drew
                 job["stage"] = 1
                 if not job["decision"]:
-                    self.__dict__.pop("_prefetch", None)
+                    self._settle()
                 self.prefetch_hits = getattr(self, "prefetch_hits", 0) + 1
                 return job["decision"]
             self._drop_prefetch()
@@ -486,6 +606,7 @@ class LevelSampler:
         return bool(seen >= self.rho and self._rng.rand() < seen)
 
     def observe_external_unseen_sample(self, seeds, solvable=None):
+        self._settle_if_streaming()
         for i, seed in enumerate(seeds):
             self.running_sample_count += 1
             if not (seed in self.staging_seed_set or seed in self.working_seed_set):
@@ -524,22 +645,30 @@ class LevelSampler:
     def sample_replay_levels(self, n, update_staleness=True):
         """`_sample_replay_levels_now`, or its prefetched result when one is pending and still valid (see above)."""
         job = self.__dict__.get("_prefetch")
-        if job is not None:
-            ok = (job["stage"] == 1 and job.get("decision") and n == job["n"] and update_staleness and self._prefetch_valid(job, "rng1"))
-            self.__dict__.pop("_prefetch", None)
+        if job is not None and job["stage"] == 2:                 # per-step draws of the rollout: the next ones of the stream
+            got = self._stream_pop(job, n) if update_staleness else None
+            if got is not None:
+                self.stream_hits = getattr(self, "stream_hits", 0) + (1 if n else 0)
+                return got
+            self._settle()
+        elif job is not None:
+            job["initial_done"].wait()
+            ok = (job["stage"] == 1 and job.get("decision") and n == job["n"] and update_staleness and "error" not in job
+                  and self._same_rng(np.random.get_state(), job["rng1"])
+                  and all(np.array_equal(getattr(self, k), job["snap"][k]) for k in self._PREFETCH_ARRAYS))
             if ok:
-                shadow = job["shadow"]
                 np.random.set_state(job["rng2"])
-                self.seed_staleness = shadow.seed_staleness
-                self._state_version = getattr(shadow, "_state_version", 0)
-                if "_score_half" in shadow.__dict__:
-                    self._score_half = shadow._score_half
+                self.seed_staleness = job["snaps"][0].copy() if job["snaps"] else job["shadow"].seed_staleness.copy()
+                self._state_version = getattr(self, "_state_version", 0) + 1
                 self.prefetch_hits = getattr(self, "prefetch_hits", 0) + 1
+                job["stage"] = 2
+                if not job["extra"]:
+                    self._settle()
                 return job["seeds_out"]
-            job["thread"].join()
+            self._settle()
         return self._sample_replay_levels_now(n, update_staleness)
 
-    def _sample_replay_levels_now(self, n, update_staleness=True):
+    def _sample_replay_levels_now(self, n, update_staleness=True, uniforms=None):
         """n sequential draws of sample_replay_level() (the runner's per-env loop, adversarial_runner.py:463) — same
         draws, same RNG consumption, same staleness bookkeeping as n separate calls, without recomputing what cannot
         change between them: seed scores are fixed during a batch of draws, so the score half of `sample_weights`
@@ -548,8 +677,10 @@ class LevelSampler:
         does: cumsum, divide by the last entry, one `random_sample`, `searchsorted(side="right")`) run per draw.
         326 -> ~40 us per draw at N = 4000: a replay rollout of 4096 envs needs 4096 draws up front."""
         rng_transforms = self.score_transform == "max" or (self.staleness_coef > 0 and self.staleness_transform == "max")
-        if n <= 1 or rng_transforms:                                # 'max' consumes the RNG inside the transform
+        if (n <= 1 and uniforms is None) or rng_transforms:         # 'max' consumes the RNG inside the transform
             return [self._sample_replay_level(update_staleness=update_staleness) for _ in range(n)]
+        if n == 0:
+            return []
         # the score half of the weights depends on seed_scores / unseen_seed_weights only, which no draw changes: a replay
         # rollout calls this once per step (256 argsorts of the buffer), so it is kept while those two arrays are unchanged
         cached = getattr(self, "_score_half", None)
@@ -573,7 +704,8 @@ class LevelSampler:
         w_scores = (1 - c) * ws if c > 0 else ws                     # constant across the batch of draws
         # 'power' with temperature 1 and eps 0 (staleness_coef > 0): (clip(s, 0) + 0) ** 1.0 is s itself, bit for bit
         plain_staleness = self.staleness_transform == "power" and self.staleness_temperature == 1.0
-        uniforms = self._rng.random_sample(n)                        # the n doubles n calls of choice(..., 1, p=w) would draw
+        if uniforms is None:
+            uniforms = self._rng.random_sample(n)                    # the n doubles n calls of choice(..., 1, p=w) would draw
         out, k = [], 0
         if c > 0 and plain_staleness and _native_draws_available():
             # the same loop in C (dcd_sampler_draws, csrc/host_utils.cpp): same IEEE operations in the same order
@@ -651,6 +783,7 @@ class LevelSampler:
         return self._sample_replay_level() if self.sample_replay_decision() else self._sample_unseen_level()
 
     def sample_weights(self):
+        self._settle_if_streaming()
         weights = self._score_transform(self.score_transform, self.temperature, self.seed_scores)
         weights = weights * (1 - self.unseen_seed_weights)
         z = np.sum(weights)

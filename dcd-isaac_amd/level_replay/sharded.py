@@ -93,11 +93,11 @@ class ShardedLevelSampler:
         d = int(bool(self.sampler.sample_replay_decision())) if self.rank == 0 else 0
         return bool(D.broadcast_ints([d], 1, group=self.group)[0])
 
-    def prefetch_next_update(self, n_local):
+    def prefetch_next_update(self, n_local, stream_extra=None):
         """LevelSampler.prefetch_next_update on rank 0 for the whole job's first draws (world x local actors, the count
-        `sample_replay_levels` will sum up); no collective: the other ranks do nothing."""
+        `sample_replay_levels` will sum up) and its share of per-step draws; no collective: the other ranks do nothing."""
         if self.rank == 0 and n_local == self.local_actors:
-            return self.sampler.prefetch_next_update(self.local_actors * self.world)
+            return self.sampler.prefetch_next_update(self.local_actors * self.world, stream_extra=(stream_extra or 0) * self.world)
         return False
 
     def sample_replay_levels(self, n, update_staleness=True):

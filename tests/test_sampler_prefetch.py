@@ -96,3 +96,44 @@ def test_prefetch_state_is_not_pickled():
     t = pickle.loads(pickle.dumps(s))
     assert "_prefetch" not in t.__dict__ and "_shadow_rng" not in t.__dict__
     s._drop_prefetch()
+
+
+@pytest.mark.parametrize("chunk,extra", [(512, 400), (16, 400), (16, 37), (7, 0)])
+def test_streamed_per_step_draws_equal_the_sequential_order(chunk, extra, monkeypatch):
+    """The per-episode re-sampling of a replay rollout asks for a few draws per step: with `stream_extra` they come from the
+    speculated continuation of the same sequential stream — across chunk boundaries (snapshot + replay of the remainder on
+    settling), beyond the speculated amount (the rest is drawn in program order) and with zero-size requests in between."""
+    from level_replay import LevelSampler
+    monkeypatch.setattr(LevelSampler, "STREAM_CHUNK", chunk)
+    B = 32
+    runs = []
+    for prefetch in (False, True):
+        np.random.seed(21)
+        s = _sampler(B, N=80)
+        req = np.random.default_rng(3)
+        log = []
+        for it in range(8):
+            if prefetch:
+                s.prefetch_next_update(B, stream_extra=extra)
+            if it == 5:
+                np.random.rand()                                     # overtaken before the decision: everything is dropped
+            d = s.sample_replay_decision()
+            seeds = s.sample_replay_levels(B) if d else None
+            steps = []
+            if d:
+                for t in range(40):
+                    n = int(req.integers(0, 6)) if t % 3 else 0      # ragged counts, many empty steps
+                    if it == 3 and t == 20:
+                        np.random.rand()                             # overtaken in the middle of the rollout: the stream must let go
+                    steps.append(s.sample_replay_levels(n))
+            w = s.sample_weights().copy()                            # a reader: sees the staleness after exactly the draws made
+            log.append((d, seeds, steps, w, _state(s)))
+            s.seed_scores[(5 * it) % 80] = np.random.rand()
+            s.after_update()
+        runs.append((log, getattr(s, "stream_hits", 0)))
+    (a, _), (b, hits) = runs
+    if extra >= 100:
+        assert hits > 100                                            # served from the stream
+    for x, y in zip(a, b):
+        assert x[0] == y[0] and x[1] == y[1] and x[2] == y[2], "decisions / seeds"
+        assert np.array_equal(x[3], y[3]) and _same(x[4], y[4])

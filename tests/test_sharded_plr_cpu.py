@@ -76,7 +76,7 @@ def _drive(sampler, store, g0, n_local, update_records, prefetch=False):
         update_records(_records(u, g0, seeds))
         sampler.after_update()
         if prefetch:                                                 # as the runner: the next update's first draws, speculatively
-            sampler.prefetch_next_update(n_local)
+            sampler.prefetch_next_update(n_local, stream_extra=2)     # 2 per env: the per-step draws come partly from the stream
         store.reconcile_seeds(set(int(x) for x in sampler.seeds if x >= 0))
         log.append((bool(replay), [int(s) for s in seeds], float(sampler.solvable_mass), float(sampler.max_score)))
     return log
@@ -98,6 +98,7 @@ def _worker(rank, world, port, out_dir):
     log = _drive(sampler, store, rank * B_LOCAL, B_LOCAL, lambda recs: sampler.update_with_records(recs, device="cpu"), prefetch=True)
     if rank == 0:
         assert getattr(sampler.sampler, "prefetch_hits", 0) >= UPDATES - 2           # the speculation was consumed, not dropped
+        assert getattr(sampler.sampler, "stream_hits", 0) >= 3
     with open(os.path.join(out_dir, f"r{rank}.pkl"), "wb") as f:
         pickle.dump({"log": log, "state": _state(sampler.sampler) if rank == 0 else None,
                      "store": (store.seed2level, store.seed2parent, store.next_seed)}, f)

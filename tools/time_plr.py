@@ -24,7 +24,7 @@ if SIM > 1:
     ls = runner.level_samplers["agent"]
     draw, pre = ls.sample_replay_levels, ls.prefetch_next_update
     ls.sample_replay_levels = lambda n, **k: draw(n * SIM, **k)[:n]
-    ls.prefetch_next_update = lambda n: pre(n * SIM)
+    ls.prefetch_next_update = lambda n, stream_extra=None: pre(n * SIM, stream_extra=(stream_extra or 0) * SIM)
 import cProfile, pstats
 prof_replay = prof_explore = False
 for j in range(12):
@@ -41,4 +41,4 @@ for j in range(12):
             pstats.Stats(pr).sort_stats("tottime").print_stats(14)
             prof_replay, prof_explore = prof_replay or rep, prof_explore or not rep
     print(json.dumps({"update": j, "replay": bool(runner.sampled_level_info["level_replay"]), "seconds": round(dt, 3),
-                      "env_steps_per_s": round(B * 256 / dt), "buffer": int(runner.level_samplers["agent"].working_seed_buffer_size), "prefetch_hits": getattr(runner.level_samplers["agent"], "prefetch_hits", 0), "sim_world": SIM}), flush=True)
+                      "env_steps_per_s": round(B * 256 / dt), "buffer": int(runner.level_samplers["agent"].working_seed_buffer_size), "prefetch_hits": getattr(runner.level_samplers["agent"], "prefetch_hits", 0), "stream_hits": getattr(runner.level_samplers["agent"], "stream_hits", 0), "sim_world": SIM}), flush=True)
