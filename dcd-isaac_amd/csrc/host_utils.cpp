@@ -323,7 +323,8 @@ int dcd_profile_begin(int32_t capacity) {
   return 0;
 }
 
-int dcd_profile_end(int32_t n_tags, int32_t* n_launches, double* total_ms, double* max_ms, void* stream) {
+int dcd_profile_end(int32_t n_tags, int32_t* n_launches, double* total_ms, double* max_ms, int32_t sample_cap, int32_t* sample_tags,
+                    float* sample_ms, void* stream) {
   dcd::g_prof_on.store(false);
   hipError_t err = hipStreamSynchronize((hipStream_t)stream);
   if (err != hipSuccess) return dcd::fail("dcd_profile_end: hipStreamSynchronize: %s", hipGetErrorString(err));
@@ -338,6 +339,7 @@ int dcd_profile_end(int32_t n_tags, int32_t* n_launches, double* total_ms, doubl
     if (n_launches) ++n_launches[t];
     if (total_ms) total_ms[t] += ms;
     if (max_ms && ms > max_ms[t]) max_ms[t] = ms;
+    if (sample_tags && sample_ms && (int32_t)i < sample_cap) { sample_tags[i] = t; sample_ms[i] = ms; }
   }
   dcd::g_prof_tag.clear();
   return 0;

@@ -187,13 +187,16 @@ class MaskedLSTMSequence(torch.autograd.Function):
     xp: [T,N,4H] input projection (+ both biases); h0, c0: [N,H]; masks: [T,N]; w_hh: [4H,H]."""
 
     @staticmethod
-    def forward(ctx, xp, h0, c0, masks, w_hh):
+    def forward(ctx, xp, h0, c0, masks, w_hh, own_xp=False):
         import ctypes as C
         from dcd_hip import check, lib, ptr, stream_ptr
         T, N, G = xp.shape
         H = G // 4
         xp, masks, c0 = xp.contiguous(), masks.contiguous().float(), c0.contiguous()
-        act = xp.clone()            # gates accumulate in place (beta = 1): addmm(xp[t], ..., out=act[t]) copied xp[t] per step
+        # gates accumulate in place (beta = 1): addmm(xp[t], ..., out=act[t]) copied xp[t] per step.  own_xp: the caller formed xp
+        # for this call only (RNN._lstm_cuda) and nothing saves it for a backward pass (a Linear's backward needs its input, not
+        # its output), so the gates overwrite it instead of a copy — 4.3 GB read + written per PPO epoch at T = 256, N = 4096
+        act = xp if own_xp else xp.clone()
         cs = torch.empty((T, N, H), device=xp.device)
         out = torch.empty((T, N, H), device=xp.device)
         hm = torch.empty((T, N, H), device=xp.device)
@@ -236,7 +239,7 @@ class MaskedLSTMSequence(torch.autograd.Function):
         d_h0 = dhm * m0 if ctx.needs_input_grad[1] else None
         d_c0 = dcf[0] * m0 if ctx.needs_input_grad[2] else None
         d_w = matmul_tn(dg.view(T * N, G), hm.view(T * N, H)) if ctx.needs_input_grad[4] else None
-        return dg, d_h0, d_c0, None, d_w
+        return dg, d_h0, d_c0, None, d_w, None
 
 
 class RNN(nn.Module):
@@ -283,9 +286,9 @@ class RNN(nn.Module):
         N = h.size(0)
         T = x.size(0) // N
         xp = linear(x, r.weight_ih_l0, r.bias_ih_l0 + r.bias_hh_l0)
-        return self.forward_projected(xp, hxs, masks)
+        return self.forward_projected(xp, hxs, masks, own_xp=True)
 
-    def forward_projected(self, xp, hxs, masks):
+    def forward_projected(self, xp, hxs, masks, own_xp=False):
         """The sequence recurrence on an input projection `xp` [T*N, 4H] = x @ W_ih^T + b_ih + b_hh that the caller
         has already formed (MultigridNetwork forms the teacher's incrementally, models/multigrid_models.py)."""
         H = self._hidden_size
@@ -294,7 +297,7 @@ class RNN(nn.Module):
         T = xp.size(0) // N
         xp = xp.view(T, N, 4 * H)
         if xp.is_cuda and _fused_lstm_enabled():
-            out, hT, cT = MaskedLSTMSequence.apply(xp, h, c, masks.view(T, N), self.rnn.weight_hh_l0)
+            out, hT, cT = MaskedLSTMSequence.apply(xp, h, c, masks.view(T, N), self.rnn.weight_hh_l0, own_xp)
             return out.view(T * N, H), (hT, cT)
         return self._lstm_cuda_unfused(xp, h, c, masks, T, N)
 

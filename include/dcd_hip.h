@@ -227,7 +227,8 @@ int dcd_mg_profile_end(DcdMg* h, int32_t* n_launches, double* total_ms, void* st
  * Process-wide, for measurement runs: do not profile while other host threads launch. */
 #define DCD_PROF_NTAGS 6
 int dcd_profile_begin(int32_t capacity);
-int dcd_profile_end(int32_t n_tags, int32_t* n_launches, double* total_ms, double* max_ms, void* stream);
+int dcd_profile_end(int32_t n_tags, int32_t* n_launches, double* total_ms, double* max_ms, int32_t sample_cap, int32_t* sample_tags,
+                    float* sample_ms, void* stream);   /* sample_*: optional, every launch in issue order (tag, duration in ms) */
 
 /* ---- state readback -------------------------------------------------------- */
 /* venv.get_encodings (parallel_wrappers.py:420-421 → adversarial.py:162-164):

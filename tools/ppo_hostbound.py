@@ -20,4 +20,4 @@ for name in ("agent", "adversary_env"):
     dev_us = sum(e.device_time for e in prof.key_averages() for _ in [0] if False) or sum(k.self_device_time_total for k in prof.key_averages())
     n_launch = sum(k.count for k in prof.key_averages() if k.self_device_time_total > 0)
     print(f"{name}: update wall {wall*1e3:.1f} ms; summed device time {dev_us/1e3:.1f} ms; ops with device time {n_launch}", flush=True)
-    print(prof.key_averages().table(sort_by="self_device_time_total", row_limit=12, max_name_column_width=50))
+    print(prof.key_averages().table(sort_by="self_device_time_total", row_limit=28, max_name_column_width=70))
