@@ -508,6 +508,12 @@ def end_to_end_leg(B, T, device, updates):
 
 def main():
     args = parse()
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes a five-line version banner to fd 1 when the first
+    # communicator is created (seen with --rccl-single; it would precede rank 0's line in every multi-GPU run).  Everything that
+    # goes to fd 1 from here on lands on stderr; the line itself is written to the original stdout at the end.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -642,7 +648,8 @@ def main():
                                    "S_train_true_env_steps_per_s": e2e["S_train_true_env_steps_per_s"],
                                    "S_train_sps_reference_formula": e2e["S_train_sps_reference_formula"],
                                    "note": "rollout with the policy in the loop / full PAIRED update incl. 3 PPO updates (end_to_end)"}
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
