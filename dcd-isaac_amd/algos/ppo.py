@@ -151,6 +151,30 @@ class PPO:
                 total += p.grad.data.norm(2).item() ** 2
         return total ** 0.5
 
+    def _losses(self, rollouts, obs_b, hxs_b, actions_b, value_preds_b, return_b, masks_b, old_logp_b, adv_b):
+        """[value loss, action loss, entropy] of one minibatch — the expressions of `update`, for its forward-only form."""
+        values, logp, dist_entropy, _ = self.actor_critic.evaluate_actions(obs_b, hxs_b, masks_b, actions_b)
+        ratio = torch.exp(logp - old_logp_b)
+        surr1 = ratio * adv_b
+        surr2 = torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param) * adv_b
+        action_loss = -torch.min(surr1, surr2).mean()
+        if rollouts.use_popart:
+            self.actor_critic.popart.update(return_b, group=self.process_group)
+            return_b = self.actor_critic.popart.normalize(return_b)
+        if self.clip_value_loss:
+            clipped = value_preds_b + (values - value_preds_b).clamp(-self.clip_param, self.clip_param)
+            value_loss = 0.5 * torch.max((values - return_b).pow(2), (clipped - return_b).pow(2)).mean()
+        else:
+            value_loss = F.smooth_l1_loss(values, return_b)
+        return torch.stack([value_loss, action_loss, dist_entropy])
+
+    def _sync_stats(self, stats):
+        """Job-wide means of the three loss statistics when no gradient exchange carries them."""
+        if not self.distributed:
+            return stats
+        self._all_reduce(stats)
+        return stats / self.world_size
+
     # ---- update -------------------------------------------------------------------------------
     def update(self, rollouts, discard_grad=False):
         value_preds = rollouts.denorm_value_preds if rollouts.use_popart else rollouts.value_preds      # ppo.py:62-65
@@ -158,10 +182,25 @@ class PPO:
         advantages = self._normalize_advantages(advantages)
         value_loss_epoch = action_loss_epoch = dist_entropy_epoch = 0.0
         grad_norms = []
+        # discard_grad (robust PLR's exploratory updates, ppo.py:129-130): the reference runs the backward pass and throws the
+        # gradients away.  Nothing observable depends on them unless their norm is logged — the parameters stay, the losses come
+        # from the forward pass — so the backward pass, the gradient exchange and the clipping are skipped and the forward pass
+        # runs without an autograd graph.  Every epoch's forward pass still runs (its minibatch permutation sums the same terms
+        # in another order) and the generator still draws its permutations: losses, PopArt state and the position of torch's
+        # generator are what they would have been (tests/test_models_ppo_vs_reference.py, test_gpu_runner.py).
+        forward_only = bool(discard_grad and not self.log_grad_norm)
         for _ in range(self.ppo_epoch):
             gen = (rollouts.recurrent_generator(advantages, self.num_mini_batch) if self.actor_critic.is_recurrent
                    else rollouts.feed_forward_generator(advantages, self.num_mini_batch))
             for (obs_b, hxs_b, actions_b, value_preds_b, return_b, masks_b, old_logp_b, adv_b) in gen:
+                if forward_only:
+                    with torch.no_grad():
+                        v, a, e = self._sync_stats(self._losses(rollouts, obs_b, hxs_b, actions_b, value_preds_b, return_b, masks_b,
+                                                                old_logp_b, adv_b)).tolist()
+                    value_loss_epoch += v
+                    action_loss_epoch += a
+                    dist_entropy_epoch += e
+                    continue
                 values, logp, dist_entropy, _ = self.actor_critic.evaluate_actions(obs_b, hxs_b, masks_b, actions_b)
                 ratio = torch.exp(logp - old_logp_b)
                 surr1 = ratio * adv_b

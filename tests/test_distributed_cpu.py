@@ -308,3 +308,25 @@ def test_popart_moments_are_job_wide():
     for k, v in pa.state_dict().items():
         assert torch.equal(a[k], b[k]), k
         np.testing.assert_allclose(a[k].numpy(), v.numpy(), rtol=2e-6, atol=1e-9, err_msg=k)
+
+
+def test_discarded_update_without_backward_equals_the_one_with():
+    """PPO.update(discard_grad=True) skips the backward pass unless gradient norms are logged: same losses, same (untouched)
+    weights, same position of torch's generator as the update that computes and discards the gradients (ppo.py:129-130)."""
+    for p in (ROOT, os.path.join(ROOT, "dcd-isaac_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(G, "ppo.npz"))
+    out = []
+    for log_norm in (True, False):
+        agent, net = _build(g, [0, 1, 2, 3], None)
+        agent.algo.log_grad_norm = log_norm
+        before = {k: v.clone() for k, v in net.state_dict().items()}
+        torch.manual_seed(2)
+        vl, al, ent, info = agent.algo.update(agent.storage, discard_grad=True)
+        out.append((vl, al, ent, torch.get_rng_state().clone()))
+        for k, v in net.state_dict().items():
+            assert torch.equal(v, before[k]), k
+        assert ("grad_norms" in info) == log_norm
+    assert out[0][:3] == out[1][:3] and torch.equal(out[0][3], out[1][3])

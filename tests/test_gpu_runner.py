@@ -123,6 +123,28 @@ def test_prefetched_replay_draws_equal_the_sequential_order(monkeypatch):
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and torch.equal(a[4], b[4])
 
 
+def test_exploratory_updates_without_backward_equal_the_ones_with():
+    """Robust PLR's exploratory updates discard their gradients; without gradient-norm logging the backward pass is skipped
+    (PPO.update, forward-only).  Losses, decisions, seeds and weights over ten updates equal the run that computes them."""
+    out = {}
+    for log_norm in (True, False):
+        args = make_args(ued_algo="domain_randomization", use_plr=True, use_reset_random_dr=True, no_exploratory_grad_updates=True,
+                         level_replay_strategy="positive_value_loss", level_replay_score_transform="rank", level_replay_prob=0.5,
+                         level_replay_rho=0.2, level_replay_seed_buffer_size=100, staleness_coef=0.3, recurrent_adversary_env=False,
+                         num_steps=64, env_name="MultiGrid-MiniGoalLastAdversarial-v0", log_grad_norm=log_norm)
+        runner, venv = build(args)
+        np.random.seed(6)
+        log = []
+        for j in range(10):
+            s = runner.run()
+            log.append((bool(runner.sampled_level_info["level_replay"]), list(runner.current_level_seeds), s["agent_value_loss"],
+                        s["agent_pg_loss"], s["agent_dist_entropy"]))
+        out[log_norm] = (log, torch.cat([p.detach().flatten() for p in runner.agents["agent"].algo.actor_critic.parameters()]).clone())
+        venv.close()
+    assert out[True][0] == out[False][0] and torch.equal(out[True][1], out[False][1])
+    assert any(x[0] for x in out[True][0]) and not all(x[0] for x in out[True][0])
+
+
 def test_accel_edits_levels():
     args = make_args(ued_algo="domain_randomization", use_plr=True, use_reset_random_dr=True, no_exploratory_grad_updates=True,
                      use_editor=True, level_editor_prob=1.0, num_edits=5, base_levels="easy",
