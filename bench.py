@@ -376,8 +376,8 @@ def pass_kernel_times(ps, passes=8):
     attached to each dispatch by hipExtLaunchKernelGGL, no tracer attached), over `passes` eager passes of the benchmark
     workload on the current stream.  Per kernel: launches per pass, mean / median / maximum duration; `sum_ms_per_pass` (from the
     means) and `sum_ms_per_pass_median` are what a pass would take with no gap between its kernels.  The timed region replays
-    the same kernels from a HIP graph; an eager launch of the step kernel measures 0 - 6 % longer than a replayed one (the
-    sum of the means can exceed `ms_per_step` by that much, the sum of the medians does not)."""
+    the same kernels back to back from a HIP graph; the sum of the eager medians lands within +- 2 % of `ms_per_step` (the means
+    carry the occasional 15 - 30 us outlier of an eager launch and sit 3 - 5 % higher)."""
     import ctypes as C
     lib = ps.dcd_hip.lib()
     n = len(PASS_KERNELS)
@@ -621,7 +621,12 @@ def main():
                          "note": f"one launch moves {algo / 1e6:.2f} MB: latency-bound at this batch (DESIGN.md §3); roofline_large_b: the same kernel where it is HBM-bound"},
         }
         kernel_times["ms_per_step_measured"] = dt / args.steps * 1e3
-        kernel_times["fits"] = kernel_times["sum_ms_per_pass_median"] <= dt / args.steps * 1e3
+        # do the per-kernel times account for the timed region?  The pass replays these kernels back to back from a HIP graph; the
+        # same kernels launched eagerly measure within a few per cent of that (begin -> end of a dispatch, no gaps counted), in
+        # either direction from run to run: the check is |sum of medians - ms_per_step| <= 3 %
+        ms = dt / args.steps * 1e3
+        kernel_times["accounts_for"] = kernel_times["sum_ms_per_pass_median"] / ms
+        kernel_times["fits"] = abs(kernel_times["accounts_for"] - 1.0) <= 0.03
         line["kernel_times"] = kernel_times
         line["roofline"]["timing"] = ("avg_launch_us: HIP start/stop events on each mg_step_kernel dispatch over one eager student rollout "
                                       "(step_kernel_profile); kernel_times lists the same measurement for every kernel of the pass")
