@@ -555,7 +555,8 @@ class LevelSampler:
                 uni = self._stream_uniforms(job, a * C, r)
                 tmp._shadow_rng = None
                 again = tmp._sample_replay_levels_now(r, True, uniforms=uni)
-                assert again == job["q_seeds"][a * C:a * C + r], "replay of the speculated draws diverged"
+                if again != job["q_seeds"][a * C:a * C + r]:
+                    raise RuntimeError("LevelSampler: the replay of the speculated draws diverged from the draws that were handed out")
             self.seed_staleness = tmp.seed_staleness
             self._state_version = getattr(self, "_state_version", 0) + 1
 
