@@ -403,7 +403,7 @@ def pass_kernel_times(ps, passes=8):
             "passes": passes, "kernels": out, "sum_ms_per_pass": total, "sum_ms_per_pass_median": total_med}
 
 
-def sweep_large_b(device, obs="u8", sizes=(65536, 1048576), iters=30):
+def sweep_large_b(device, obs="u8", sizes=(65536, 262144, 1048576), iters=30):
     """dcd_mg_step alone at large B (HBM-bound regime), same outputs as the benchmark step."""
     import dcd_hip
     res = []
