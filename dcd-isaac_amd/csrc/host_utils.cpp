@@ -311,6 +311,7 @@ extern "C" {
 int dcd_profile_begin(int32_t capacity) {
   if (capacity <= 0 || capacity > (1 << 20)) return dcd::fail("dcd_profile_begin: bad capacity %d", capacity);
   std::lock_guard<std::mutex> lk(dcd::g_prof_mu);
+  if (dcd::g_prof_on.load()) return dcd::fail("dcd_profile_begin: a profile is already open (the state is process-global)");
   while ((int)dcd::g_prof_ev.size() < 2 * capacity) {
     hipEvent_t e;
     hipError_t err = hipEventCreate(&e);
@@ -330,6 +331,7 @@ int dcd_profile_end(int32_t n_tags, int32_t* n_launches, double* total_ms, doubl
   if (err != hipSuccess) return dcd::fail("dcd_profile_end: hipStreamSynchronize: %s", hipGetErrorString(err));
   std::lock_guard<std::mutex> lk(dcd::g_prof_mu);
   for (int t = 0; t < n_tags; ++t) { if (n_launches) n_launches[t] = 0; if (total_ms) total_ms[t] = 0.0; if (max_ms) max_ms[t] = 0.0; }
+  int32_t n_out = 0;                          // samples are COMPACTED: entry n_out is the n_out-th launch with a tag < n_tags
   for (size_t i = 0; i < dcd::g_prof_tag.size(); ++i) {
     const int t = dcd::g_prof_tag[i];
     if (t < 0 || t >= n_tags) continue;
@@ -339,7 +341,7 @@ int dcd_profile_end(int32_t n_tags, int32_t* n_launches, double* total_ms, doubl
     if (n_launches) ++n_launches[t];
     if (total_ms) total_ms[t] += ms;
     if (max_ms && ms > max_ms[t]) max_ms[t] = ms;
-    if (sample_tags && sample_ms && (int32_t)i < sample_cap) { sample_tags[i] = t; sample_ms[i] = ms; }
+    if (sample_tags && sample_ms && n_out < sample_cap) { sample_tags[n_out] = t; sample_ms[n_out] = ms; ++n_out; }
   }
   dcd::g_prof_tag.clear();
   return 0;

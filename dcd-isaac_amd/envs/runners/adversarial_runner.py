@@ -45,6 +45,21 @@ class RunningMeanStd:
         self.mean, self.var, self.count = self.mean + delta * b_count / tot, m2 / tot, tot
 
 
+def _startup_env(name):
+    """The value `name` had when the process STARTED (/proc/self/environ: the initial environment block, which later
+    os.environ / setenv writes do not touch).  hipBLASLt reads TENSILE_STREAMK_DATA_PARALLEL once per process, so a value set
+    from Python after the first GEMM would pass an os.environ check and still deadlock the GPU."""
+    try:
+        with open("/proc/self/environ", "rb") as f:
+            for item in f.read().split(b"\0"):
+                k, _, v = item.partition(b"=")
+                if k == name.encode():
+                    return v.decode()
+        return None
+    except OSError:
+        return os.environ.get(name)
+
+
 class AdversarialRunner:
     def __init__(self, args, venv, agent, ued_venv=None, adversary_agent=None, adversary_env=None,
                  flexible_protagonist=False, train=False, plr_args=None, device="cpu", process_group=None):
@@ -68,7 +83,7 @@ class AdversarialRunner:
         # DCD_CONCURRENT_PPO=1 (opt-in): the PPO updates of one run() on three streams (_flush_updates).  Refused unless the
         # process was started with TENSILE_STREAMK_DATA_PARALLEL=1: GEMMs of several streams deadlock otherwise (see there).
         self._concurrent_updates = not self.distributed and os.environ.get("DCD_CONCURRENT_PPO", "0") == "1"
-        if self._concurrent_updates and os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") != "1":
+        if self._concurrent_updates and _startup_env("TENSILE_STREAMK_DATA_PARALLEL") != "1":
             raise ValueError("DCD_CONCURRENT_PPO=1 needs TENSILE_STREAMK_DATA_PARALLEL=1 in the environment the process STARTS with: "
                              "hipBLASLt's StreamK GEMMs spin on flags between workgroups and deadlock when GEMMs of several streams "
                              "are in flight (profiles/r03_concurrent_ppo_hang.log); the library reads the variable once")

@@ -349,6 +349,13 @@ class HipAdversarialVecEnv:
             return [e for e in enc]
         return [enc[i] for i in index]
 
+    def get_level(self):
+        """venv.get_level() (parallel_wrappers.py:418-420: `[l[0] for l in remote_attr('level')]`; callers train.py:207 and
+        adversarial_runner.py:376, both on the non-MultiGrid branch).  The reference's MultiGrid env defines no `level`
+        attribute — there the call raises in the worker; here it returns each env's level in the form `reset_to_level`
+        takes back (adversarial.py:271-294): the uint8[S,S,3] encoding, so get_level -> reset_to_level_batch round-trips."""
+        return self.get_encodings()
+
     def get_encodings_device(self):
         return self.engine.get_encodings()
 
@@ -376,7 +383,7 @@ class HipAdversarialVecEnv:
     def remote_attr(self, name, data=None, flatten=False, index=None):
         table = {"encoding": self.get_encodings, "n_clutter_placed": self.get_num_blocks, "passable": self.get_passable,
                  "shortest_path_length": self.get_shortest_path_length, "distance_to_goal": self.get_distance_to_goal,
-                 "seed_value": self.get_seed}
+                 "seed_value": self.get_seed, "level": lambda: [[e] for e in self.get_encodings()]}
         if name == "seed" and data is not None:
             return self.set_seed(data)
         if name not in table:

@@ -464,6 +464,9 @@ class LevelSampler:
                 if job["decision"]:
                     job["seeds_out"] = shadow._sample_replay_levels_now(job["n"], True)
                     job["rng2"] = shadow._shadow_rng.get_state()
+                    # the consumer installs THIS copy: once the event is set the thread goes on mutating / rebinding
+                    # shadow.seed_staleness with streamed draws, so the shadow itself is never read from the other side
+                    job["stale_after_initial"] = shadow.seed_staleness.copy()
                     job["initial_done"].set()
                     self._stream_ahead(job, shadow)
             except BaseException as exc:                          # noqa: BLE001  (a failed speculation is simply not used)
@@ -484,7 +487,7 @@ class LevelSampler:
         """Thread side: draws n_initial+1, n_initial+2, ... on the shadow, in chunks, until `extra` are out or the stream is stopped."""
         rec = _RecordingRng(shadow._shadow_rng)
         shadow._shadow_rng = rec
-        job["snaps"].append(shadow.seed_staleness.copy())          # staleness after the initial draws = before chunk 0
+        job["snaps"].append(job["stale_after_initial"])            # staleness after the initial draws = before chunk 0
         while job["produced"] < job["extra"] and not job["stop"]:
             c = min(self.STREAM_CHUNK, job["extra"] - job["produced"])
             rec.doubles, rec.unsafe = [], False
@@ -623,6 +626,7 @@ class LevelSampler:
                     self._update_staleness(seed_idx)
 
     def sample_replay_level(self, update_staleness=True):
+        self._settle_if_streaming()
         return self._sample_replay_level(update_staleness=update_staleness)
 
     def _replay_distribution(self):
@@ -659,7 +663,7 @@ class LevelSampler:
                   and all(np.array_equal(getattr(self, k), job["snap"][k]) for k in self._PREFETCH_ARRAYS))
             if ok:
                 np.random.set_state(job["rng2"])
-                self.seed_staleness = job["snaps"][0].copy() if job["snaps"] else job["shadow"].seed_staleness.copy()
+                self.seed_staleness = job["stale_after_initial"].copy()
                 self._state_version = getattr(self, "_state_version", 0) + 1
                 self.prefetch_hits = getattr(self, "prefetch_hits", 0) + 1
                 job["stage"] = 2
@@ -756,6 +760,7 @@ class LevelSampler:
         return out
 
     def _sample_unseen_level(self):
+        self._settle_if_streaming()
         if self.sample_full_distribution:
             seed = int(np.random.randint(1, INT32_MAX))
             while seed in self.staging_seed_set or seed in self.working_seed_set:
@@ -772,6 +777,7 @@ class LevelSampler:
     def sample(self, strategy=None):
         if strategy == "full_distribution":
             raise ValueError("One-off sampling via full_distribution strategy is not supported.")
+        self._settle_if_streaming()
         self.running_sample_count += 1
         strategy = strategy or self.strategy
         if not self.sample_full_distribution:
@@ -852,6 +858,7 @@ class LevelSampler:
         return max(self.seed_scores)
 
     def __getstate__(self):                    # checkpoints pickle the sampler (adversarial_runner.py:214)
+        self._settle_if_streaming()            # an open stream's staleness is installed before the state is copied
         d = dict(self.__dict__)
         d["_scorer"] = None
         d.pop("_prefetch", None)

@@ -97,7 +97,7 @@ class _AllowListPickle:
     collections.deque (`agent_returns`, adversarial_runner.py:206), which every runner checkpoint holds."""
     import pickle as _pickle
     __name__ = "dcd_allow_list_pickle"
-    load, loads, dump, dumps = _pickle.load, _pickle.loads, _pickle.dump, _pickle.dumps
+    dump, dumps = _pickle.dump, _pickle.dumps
     Pickler, UnpicklingError, PickleError = _pickle.Pickler, _pickle.UnpicklingError, _pickle.PickleError
     HIGHEST_PROTOCOL, DEFAULT_PROTOCOL = _pickle.HIGHEST_PROTOCOL, _pickle.DEFAULT_PROTOCOL
     _allowed = None
@@ -111,6 +111,17 @@ class _AllowListPickle:
                 raise pickle.UnpicklingError(f"checkpoint names {module}.{name}, which is not on the allow-list of "
                                              f"util.load_checkpoint_safe: refused (nothing from the file was executed)")
             return super().find_class(module, name)
+
+    # torch.load's LEGACY (non-zip) path reads the header pickles (magic number, protocol, sys_info) and the tar-format members
+    # through `pickle_module.load(f)` — the module-level functions, not `Unpickler`: they must be restricted as well.
+    @staticmethod
+    def load(file, **kwargs):
+        return _AllowListPickle.Unpickler(file, **kwargs).load()
+
+    @staticmethod
+    def loads(data, **kwargs):
+        import io
+        return _AllowListPickle.Unpickler(io.BytesIO(data), **kwargs).load()
 
 
 def load_checkpoint_safe(path, map_location=None):

@@ -228,7 +228,10 @@ int dcd_mg_profile_end(DcdMg* h, int32_t* n_launches, double* total_ms, void* st
 #define DCD_PROF_NTAGS 6
 int dcd_profile_begin(int32_t capacity);
 int dcd_profile_end(int32_t n_tags, int32_t* n_launches, double* total_ms, double* max_ms, int32_t sample_cap, int32_t* sample_tags,
-                    float* sample_ms, void* stream);   /* sample_*: optional, every launch in issue order (tag, duration in ms) */
+                    float* sample_ms, void* stream);   /* sample_*: optional; the launches with a tag < n_tags in issue order,
+                                                          COMPACTED (entry k = the k-th such launch: tag, duration in ms),
+                                                          sum(n_launches) entries (at most sample_cap).  begin() fails while a
+                                                          profile is open: the state is process-global. */
 
 /* ---- state readback -------------------------------------------------------- */
 /* venv.get_encodings (parallel_wrappers.py:420-421 → adversarial.py:162-164):

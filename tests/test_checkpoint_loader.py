@@ -58,3 +58,42 @@ def test_foreign_globals_are_refused_not_executed(tmp_path, payload):
     torch.save({"runner_state_dict": {"agent_state_dict": {"agent": {}}, "x": payload}}, path)
     with pytest.raises(pickle.UnpicklingError, match="allow-list"):
         load_checkpoint_safe(path, map_location="cpu")
+
+
+class _Marker:
+    """reduce -> open(path, 'w'): the side effect a hostile stream would have if any of its pickles were executed."""
+    def __init__(self, path):
+        self.path = path
+
+    def __reduce__(self):
+        return (open, (self.path, "w"))
+
+
+@pytest.mark.parametrize("form", ["raw_header", "legacy_save"])
+def test_hostile_legacy_format_streams_are_refused_not_executed(tmp_path, form):
+    """torch.load's LEGACY (non-zip) path reads its header pickles and members through `pickle_module.load(f)`, not through
+    `pickle_module.Unpickler`: both must go through the allow-list.  `raw_header`: a file whose FIRST pickle is
+    the payload (what torch reads as the magic number); `legacy_save`: a well-formed `_use_new_zipfile_serialization=False`
+    file with the payload inside the object pickle."""
+    from util import load_checkpoint_safe
+    marker = os.path.join(tmp_path, "ran")
+    path = os.path.join(tmp_path, "evil_legacy.tar")
+    if form == "raw_header":
+        with open(path, "wb") as f:
+            pickle.dump(_Marker(marker), f, protocol=2)
+            pickle.dump(1001, f, protocol=2)
+    else:
+        torch.save({"runner_state_dict": {"x": _Marker(marker)}}, path, _use_new_zipfile_serialization=False)
+    with pytest.raises(pickle.UnpicklingError, match="allow-list"):
+        load_checkpoint_safe(path, map_location="cpu")
+    assert not os.path.exists(marker)
+
+
+def test_benign_legacy_format_checkpoint_still_loads(tmp_path):
+    from util import load_checkpoint_safe
+    path = os.path.join(tmp_path, "legacy.tar")
+    net = torch.nn.Linear(3, 2)
+    torch.save({"runner_state_dict": {"agent_state_dict": {"agent": net.state_dict()}, "num_updates": 7}}, path,
+               _use_new_zipfile_serialization=False)
+    out = load_checkpoint_safe(path, map_location="cpu")["runner_state_dict"]
+    assert out["num_updates"] == 7 and torch.equal(out["agent_state_dict"]["agent"]["weight"], net.state_dict()["weight"])

@@ -31,3 +31,17 @@ def test_one_json_line_with_roofline_and_kernel_times():
     assert kt["mg_step_kernel"]["launches_per_pass"] == 256 and kt["mg_level_kernel"]["launches_per_pass"] == 30
     assert 0.9 < d["kernel_times"]["accounts_for"] < 1.15                 # the per-kernel event times account for the replayed pass
     assert d["grad_exchange"]["bytes"] > 9e7                               # the gradient all-reduce leg ran through RCCL
+
+
+def test_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as the driver records it (no torch.distributed.run): the parent starts the two ranks itself —
+    here both on the box's one GPU over gloo — and relays rank 0's single line (VERDICT r3 missing #1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-train-leg", "--no-sweep"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 1e8

@@ -85,6 +85,10 @@ def test_concurrent_updates_are_refused_with_streamk_gemms(monkeypatch):
     monkeypatch.delenv("TENSILE_STREAMK_DATA_PARALLEL", raising=False)
     with pytest.raises(ValueError, match="TENSILE_STREAMK_DATA_PARALLEL"):
         build(make_args(ued_algo="paired"))
+    # set from Python AFTER the process started: the library has read its value already, the guard looks at the start-up block
+    monkeypatch.setenv("TENSILE_STREAMK_DATA_PARALLEL", "1")
+    with pytest.raises(ValueError, match="TENSILE_STREAMK_DATA_PARALLEL"):
+        build(make_args(ued_algo="paired"))
     monkeypatch.delenv("DCD_CONCURRENT_PPO")
     runner, venv = build(make_args(ued_algo="paired"))
     assert not runner._concurrent_updates                           # the default: program order
