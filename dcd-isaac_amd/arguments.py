@@ -73,3 +73,5 @@ for _name, _type, _default in _FLAGS:
         parser.add_argument(f"--{_name}", type=_type, default=_default)
 # additions of this engine
 parser.add_argument("--device", type=str, default=None, help="HIP device (default cuda:LOCAL_RANK)")
+parser.add_argument("--wall_limit_s", type=float, default=0.0,
+                    help="stop after this many seconds of training: checkpoint and exit (resume with --checkpoint true)")

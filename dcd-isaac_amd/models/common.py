@@ -82,8 +82,9 @@ class _LinearSplitK(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None):
-    """F.linear for 2-D inputs; on the PPO batch (>= 65 536 rows on the GPU) with the split-K weight gradient."""
-    if x.is_cuda and x.dim() == 2 and x.size(0) >= 65536 and torch.is_grad_enabled():
+    """F.linear for 2-D inputs; on the PPO batch (>= MATMUL_TN_MIN_ROWS = 65 536 rows on the GPU) with the split-K weight
+    gradient.  (tests/test_gpu_ppo_vs_reference.py lowers the threshold so that a fixture of 1 024 rows takes this branch.)"""
+    if x.is_cuda and x.dim() == 2 and x.size(0) >= MATMUL_TN_MIN_ROWS and torch.is_grad_enabled():
         return _LinearSplitK.apply(x, weight, bias)
     return F.linear(x, weight, bias)
 

@@ -347,6 +347,127 @@ def gen_ppo():
     print("teacher_shapes.npz")
 
 
+def _roll_and_update(net, st, agent, tape, T, masks, bad, rewards, out, seeds=(1, 2)):
+    """Rolls the REFERENCE policy over a fixed observation tape (its own sampled actions are stored; they do not feed back into
+    the tape), computes returns with proper time limits and runs ONE reference PPO update.  tape(t) -> obs dict of step t."""
+    for k, v in tape(0).items():
+        st.obs[k][0].copy_(v)
+    torch.manual_seed(seeds[0])
+    vals, acts, dists = [], [], []
+    for t in range(T):
+        with torch.no_grad():
+            v, a, ld, h = agent.act(st.get_obs(t), st.get_recurrent_hidden_state(t), st.masks[t])
+        lp = ld.gather(-1, a)
+        vals.append(v.numpy().copy()); acts.append(a.numpy().copy()); dists.append(ld.numpy().copy())
+        agent.insert(tape(t + 1), h, a, lp, ld, v, torch.from_numpy(rewards[t]), torch.from_numpy(masks[t + 1]),
+                     torch.from_numpy(bad[t + 1]))
+    with torch.no_grad():
+        nv = agent.get_value(st.get_obs(-1), st.get_recurrent_hidden_state(-1), st.masks[-1])
+    st.compute_returns(nv, True, 0.995, 0.95)
+    out.update(masks=masks, bad_masks=bad, rewards=rewards, act_values=np.stack(vals), act_actions=np.stack(acts),
+               act_logdist=np.stack(dists), next_value=nv.numpy().copy(), returns=st.returns.numpy().copy(),
+               action_log_probs=st.action_log_probs.numpy().copy(), hidden0=st.recurrent_hidden_states[0].numpy().copy(),
+               hidden1=st.recurrent_hidden_states[1].numpy().copy(), hiddenT=st.recurrent_hidden_states[T].numpy().copy())
+    if st.truncated_value_preds is not None:
+        out["truncated_value_preds"] = st.truncated_value_preds.numpy().copy()
+    torch.manual_seed(seeds[1])
+    vl, al, ent, info = agent.update()
+    out.update(ppo_value_loss=np.array(vl), ppo_action_loss=np.array(al), ppo_entropy=np.array(ent),
+               ppo_grad_norms=np.array(info["grad_norms"]))
+
+
+def gen_ppo_wide():
+    """Student PPO at a width where the GPU product path's large-batch branches engage when their row thresholds are lowered
+    (split-K weight gradients need >= 512 rows per minibatch: T = 32, B = 32, two minibatches of 16 envs).  Initial weights:
+    the reference's own seed-0 initialisation already held in ppo.npz.  Observations are stored as the engine's raw bytes
+    ([vx][vy][c] + direction); the reference sees them as VecPreprocessImageWrapper would hand them over (k / 10, CHW)."""
+    from algos import RolloutStorage, PPO, ACAgent
+    from models import MultigridNetwork
+    obs_space, act_space = student_spaces()
+    g0 = np.load(os.path.join(OUT, "ppo.npz"))
+    net = MultigridNetwork(observation_space=obs_space, action_space=act_space, scalar_fc=5, scalar_dim=4,
+                           recurrent_arch="lstm", recurrent_hidden_size=256)
+    net.load_state_dict({k[2:]: torch.from_numpy(g0[k]) for k in g0.files if k.startswith("w_") and not k.startswith("w_after_")})
+    T, B = 32, 32
+    rng = np.random.default_rng(11)
+    img8 = rng.integers(0, 11, (T + 1, B, 5, 5, 3)).astype(np.uint8)
+    dir8 = rng.integers(0, 4, (T + 1, B)).astype(np.uint8)
+    trunc_img8 = rng.integers(0, 11, (T + 1, B, 5, 5, 3)).astype(np.uint8)
+    trunc_dir8 = rng.integers(0, 4, (T + 1, B)).astype(np.uint8)
+    f32 = lambda im: torch.from_numpy((im.astype(np.float64) / 10.0).astype(np.float32).transpose(*range(im.ndim - 3), -1, -3, -2).copy())
+    masks = (rng.random((T + 1, B, 1)) > 0.08).astype(np.float32)
+    masks[0] = 1
+    masks[T] = 0
+    bad = np.ones_like(masks)
+    bad[(masks == 0) & (rng.random(masks.shape) < 0.6)] = 0
+    rewards = (rng.random((T, B, 1)) * (rng.random((T, B, 1)) < 0.1)).astype(np.float32)
+    algo = PPO(net, clip_param=0.2, ppo_epoch=2, num_mini_batch=2, value_loss_coef=0.5, entropy_coef=0.0,
+               lr=1e-4, eps=1e-5, max_grad_norm=0.5, clip_value_loss=True, log_grad_norm=True)
+    st = RolloutStorage(net, T, B, obs_space, act_space, 256, recurrent_arch="lstm", use_proper_time_limits=True)
+    agent = ACAgent(algo, st)
+    st.truncated_obs["image"].copy_(f32(trunc_img8))
+    st.truncated_obs["direction"].copy_(torch.from_numpy(trunc_dir8.astype(np.float32))[..., None])
+    tape = lambda t: {"image": f32(img8[t]), "direction": torch.from_numpy(dir8[t].astype(np.float32))[:, None]}
+    out = dict(img8=img8, dir8=dir8, trunc_img8=trunc_img8, trunc_dir8=trunc_dir8, T=np.array(T), B=np.array(B))
+    _roll_and_update(net, st, agent, tape, T, masks, bad, rewards, out)
+    for k, v in net.state_dict().items():
+        out[f"w_after_{k}"] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "ppo_wide.npz"), **out)
+    print("ppo_wide.npz", len(out), "grad norms", out["ppo_grad_norms"])
+
+
+def gen_ppo_teacher():
+    """The PAIRED teacher (recurrent_adversary_env: conv 3 -> 128 on the 15 x 15 grid, 21 692 -> LSTM 256, 169 actions;
+    22 502 732 parameters) over a constructive tape of T = 27 steps, B = 8 envs: per-step act outputs and ONE reference PPO
+    update (2 epochs, 1 minibatch).  90 MB of weights are not stored: the initial weights are `det_weights.fill_state_dict`
+    (integer hash, identical on every host); after the update every tensor but the LSTM input weight is stored whole, and of
+    that one a column sample (every 89th image column + the 60 non-image columns) plus the fp64 row / column sums of its
+    change."""
+    sys.path.insert(0, OUT)
+    import det_weights
+    from algos import RolloutStorage, PPO, ACAgent
+    from models import MultigridNetwork
+    adv_space = {"image": Box((3, 15, 15)), "time_step": Box((1,), high=27), "random_z": Box((50,), high=1)}
+    net = MultigridNetwork(observation_space=adv_space, action_space=Discrete(169), conv_filters=128, scalar_fc=10, scalar_dim=28,
+                           random_z_dim=50, recurrent_arch="lstm", recurrent_hidden_size=256)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    w0 = det_weights.fill_state_dict(shapes, gains={"actor.1.linear.weight": 0.01})
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w0.items()})
+    T, B = 27, 8
+    rng = np.random.default_rng(5)
+    enc, loc = det_weights.teacher_tape(rng, T, B)
+    z = rng.random((T + 1, B, 50)).astype(np.float32)
+    masks = np.ones((T + 1, B, 1), np.float32)
+    masks[T] = 0
+    masks[9, 2] = masks[17, 5] = 0                     # the recurrent state is cut mid-tape somewhere (the runner never does)
+    bad = np.ones_like(masks)
+    rewards = np.zeros((T, B, 1), np.float32)
+    rewards[-1] = rng.random((B, 1)).astype(np.float32)          # replace_final_return: the regret arrives at the last step
+    f32 = lambda im: torch.from_numpy((im.astype(np.float64) / 10.0).astype(np.float32).transpose(0, 3, 1, 2).copy())
+    tape = lambda t: {"image": f32(enc[t]), "time_step": torch.full((B, 1), float(t)), "random_z": torch.from_numpy(z[t])}
+    algo = PPO(net, clip_param=0.2, ppo_epoch=2, num_mini_batch=1, value_loss_coef=0.5, entropy_coef=0.0,
+               lr=1e-4, eps=1e-5, max_grad_norm=0.5, clip_value_loss=True, log_grad_norm=True)
+    st = RolloutStorage(net, T, B, adv_space, Discrete(169), 256, recurrent_arch="lstm", use_proper_time_limits=False)
+    agent = ACAgent(algo, st)
+    out = dict(enc=enc, loc=loc, random_z=z, T=np.array(T), B=np.array(B))
+    _roll_and_update(net, st, agent, tape, T, masks, bad, rewards, out, seeds=(4, 6))
+    big = "rnn.rnn.weight_ih_l0"
+    cols = np.concatenate([np.arange(0, 21632, 89), np.arange(21632, 21692)])
+    for k, v in net.state_dict().items():
+        v = v.detach().numpy()
+        if k == big:
+            d = v.astype(np.float64) - w0[k].astype(np.float64)
+            out["big_cols"] = cols
+            out["w_after_big_sample"] = v[:, cols].copy()
+            out["big_delta_rowsum"] = d.sum(1)
+            out["big_delta_colsum"] = d.sum(0)
+            out["big_delta_abs_mean"] = np.array(np.abs(d).mean())
+        else:
+            out[f"w_after_{k}"] = v.copy()
+    np.savez_compressed(os.path.join(OUT, "ppo_teacher.npz"), **out)
+    print("ppo_teacher.npz", len(out), "losses", out["ppo_value_loss"], out["ppo_action_loss"], out["ppo_entropy"], "grad norms", out["ppo_grad_norms"])
+
+
 def gen_entropy():
     """policy_entropy (level_sampler.py:278-287): `-exp(l) * l.sum(-1) / max_entropy` broadcasts [L,A] against [L], so
     the reference's expression is defined only for episodes of L == 1 or L == A steps (any other length raises).

@@ -1,0 +1,232 @@
+"""-m gpu: the PRODUCT's device path of a25 / a17 / §8f-1 against the reference's own numbers.
+
+Everything here runs on cuda:0 through the branches a GPU run takes — im2col GEMM conv (`Conv2d_tf._valid_conv_gemm`),
+split-K weight gradients (`_LinearSplitK` / `matmul_tn`), the fused masked-LSTM autograd node over `dcd_lstm_seq_fwd/bwd_step`,
+the teacher's incremental (carried) input projection in the PPO batch and — at rollout time — `StudentActor` /
+`PairedStudentActors` / `GridActor.act_storage` (fused HIP policy step on raw u8 observations, fp32 MFMA tile product) — and is
+compared with fixtures the REFERENCE produced (tests/golden/make_golden.py: gen_ppo, gen_ppo_wide, gen_ppo_teacher import
+`models.MultigridNetwork`, `algos.RolloutStorage`, `algos.PPO` from /root/reference and run them on CPU):
+
+  ppo.npz          student, T = 12, B = 4, one minibatch                 (the fixture of tests/test_models_ppo_vs_reference.py)
+  ppo_wide.npz     student, T = 32, B = 32, two minibatches of 512 rows  (split-K branches, with their row threshold lowered)
+  ppo_teacher.npz  PAIRED teacher, 22.5 M parameters, T = 27, B = 8      (carried projection, 169-way head)
+
+Tolerances, all fp32 and all against the reference's CPU arithmetic (different summation orders: rocBLAS / hipBLASLt GEMMs, split-K
+partial sums, wave reductions; hardware exp / rcp in the rollout-time activations):
+  per-step values / log-dist / hidden state, module path        rtol 1e-5, atol 2e-6
+  the same through the fused rollout kernels                    atol 5e-6 (3e-6 against the module on one step; here
+                                                                 the recurrent state is the kernels' own over the whole tape)
+  truncated value predictions                                   rtol 1e-5, atol 2e-6
+  PPO losses                                                    rtol 1e-4 (north_star's "stated fp32 tolerance")
+  gradient norms                                                rtol 1e-3
+  weights after the update (2 epochs x Adam, lr 1e-4)           atol 2e-6 = 2 % of one Adam step; the largest deviation seen
+                                                                 is printed (run with -s)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import ppo_fixtures as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ppo(net, num_mini_batch=1):
+    from algos import PPO
+    return PPO(net, clip_param=0.2, ppo_epoch=2, num_mini_batch=num_mini_batch, value_loss_coef=0.5, entropy_coef=0.0, lr=1e-4,
+               eps=1e-5, max_grad_norm=0.5, clip_value_loss=True, log_grad_norm=True)
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+# ---- student, small fixture ---------------------------------------------------------------------------------------------
+def test_student_act_and_evaluate_on_device_match_reference():
+    g = F.load("ppo.npz")
+    net = F.student_net(DEV)
+    st = F.student_storage(net, g, DEV, u8=False, wide=False)
+    T, B = 12, 4
+    hid = st.recurrent_hidden_states
+    for t in range(T):
+        with torch.no_grad():
+            v, a, ld, h = net.act(st.get_obs(t), (hid[t, :, :256], hid[t, :, 256:]), st.masks[t], deterministic=True)
+        np.testing.assert_allclose(_np(v), g["act_values"][t], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(_np(ld), g["act_logdist"][t], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(_np(torch.cat(h, -1)), g["hidden"][t + 1], rtol=1e-5, atol=2e-6)
+    flat = lambda x: x[:-1].reshape(T * B, *x.shape[2:])
+    with torch.no_grad():                                            # sequence mode: the fused LSTM node, forward
+        ev, elp, eent, _ = net.evaluate_actions({k: flat(v) for k, v in st.obs.items()}, st.get_recurrent_hidden_state(0), flat(st.masks),
+                                                st.actions.reshape(T * B, 1))
+    np.testing.assert_allclose(_np(ev), g["eval_values"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(_np(elp), g["eval_logp"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(eent.item(), g["eval_entropy"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("u8", [False, True])
+def test_student_truncated_value_preds_on_device_match_reference(u8):
+    g = F.load("ppo.npz")
+    net = F.student_net(DEV)
+    st = F.student_storage(net, g, DEV, u8=u8, wide=False)
+    np.testing.assert_allclose(_np(st._compute_truncated_value_preds()), g["truncated_value_preds"], rtol=1e-5, atol=2e-6)
+    if u8:                                                           # the derived fp32 observations ARE the reference's inputs
+        assert np.array_equal(_np(st.obs["image"]), g["img"]) and np.array_equal(_np(st.obs["direction"]), g["direction"])
+
+
+@pytest.mark.parametrize("u8", [False, True])
+def test_student_ppo_update_on_device_matches_reference(u8):
+    from algos import ACAgent
+    g = F.load("ppo.npz")
+    net = F.student_net(DEV)
+    st = F.student_storage(net, g, DEV, u8=u8, wide=False)
+    algo = _ppo(net)
+    algo.entropy_coef = 0.01                                         # gen_ppo's setting
+    torch.manual_seed(2)
+    vl, al, ent, info = ACAgent(algo, st).update()
+    worst = F.check_update(net, g, vl, al, ent, info, atol_w=2e-6)
+    print(f"student small u8={u8}: losses {vl:.6g} {al:.6g} {ent:.6g} (ref {float(g['ppo_value_loss']):.6g} {float(g['ppo_action_loss']):.6g} "
+          f"{float(g['ppo_entropy']):.6g}); max |w - w_ref| = {worst:.3g}")
+
+
+# ---- student, wide fixture: split-K branches ---------------------------------------------------------------------------------
+@pytest.fixture
+def low_splitk_threshold(monkeypatch):
+    """The large-batch branches (`linear` -> _LinearSplitK, `matmul_tn`) engage at >= 65 536 rows in production; the fixture has
+    512 rows per minibatch (4 608 conv rows), so the threshold — one module variable — is lowered for these tests."""
+    from models import common
+    monkeypatch.setattr(common, "MATMUL_TN_MIN_ROWS", 256)
+    calls = {"linear": 0, "tn": 0}
+    orig_apply, orig_tn = common._LinearSplitK.apply, common.matmul_tn
+
+    def tn(a, b):
+        if a.is_cuda and a.size(0) >= 512:
+            calls["tn"] += 1
+        return orig_tn(a, b)
+    monkeypatch.setattr(common, "matmul_tn", tn)
+    return calls
+
+
+@pytest.mark.parametrize("u8", [False, True])
+def test_student_wide_update_through_splitk_matches_reference(u8, low_splitk_threshold):
+    from algos import ACAgent
+    g = F.load("ppo_wide.npz")
+    net = F.student_net(DEV)
+    st = F.student_storage(net, g, DEV, u8=u8, wide=True)
+    # the storage holds the reference's hidden states only for step 0 (all an update reads); the truncated-value pass reads the
+    # states at the truncated steps: fill them by rolling the module over the tape first
+    h = st.recurrent_hidden_states[0]
+    for t in range(st.num_steps):
+        with torch.no_grad():
+            v, a, ld, hc = net.act(st.get_obs(t), (h[:, :256], h[:, 256:]), st.masks[t], deterministic=True)
+        np.testing.assert_allclose(_np(v), g["act_values"][t], rtol=1e-5, atol=2e-6)
+        h = torch.cat(hc, -1)
+        st.recurrent_hidden_states[t + 1].copy_(h)
+    np.testing.assert_allclose(_np(h), g["hiddenT"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(_np(st._compute_truncated_value_preds()), g["truncated_value_preds"], rtol=1e-5, atol=2e-6)
+    torch.manual_seed(2)
+    vl, al, ent, info = ACAgent(_ppo(net, num_mini_batch=2), st).update()
+    assert low_splitk_threshold["tn"] >= 4 * 3                       # per minibatch: conv, LSTM input, dW_hh (+ heads) went split-K
+    worst = F.check_update(net, g, vl, al, ent, info, atol_w=2e-6)
+    print(f"student wide u8={u8}: losses {vl:.6g} {al:.6g} {ent:.6g}; split-K contractions {low_splitk_threshold['tn']}; "
+          f"max |w - w_ref| = {worst:.3g}")
+
+
+def test_fused_student_rollout_step_matches_reference_tape():
+    """`StudentActor.act_storage` (dcd_policy_features_u8 -> GEMM -> dcd_policy_cell_heads) over the reference's observation tape,
+    the recurrent state being the kernels' own from step to step: values, log-distributions and the final (h, c) against what
+    the reference's `act` produced on the same tape; then the same through `PairedStudentActors` (both students per launch)."""
+    from dcd_hip.policy import PairedStudentActors, StudentActor
+    g = F.load("ppo_wide.npz")
+    T, B = int(g["T"]), int(g["B"])
+    nets = [F.student_net(DEV), F.student_net(DEV)]
+    sts = [F.student_storage(n, g, DEV, u8=True, wide=True) for n in nets]
+    for s in sts:
+        s.value_preds.zero_(); s.action_log_dist.zero_(); s.recurrent_hidden_states[1:].zero_()
+    fa = StudentActor.try_create(nets[0], B, seed=3)
+    fa.begin_rollout(T)
+    for t in range(T):
+        fa.act_storage(sts[0], t)
+    torch.cuda.synchronize()
+
+    def check(st, what):
+        np.testing.assert_allclose(_np(st.value_preds[:-1]), g["act_values"], rtol=1e-5, atol=5e-6, err_msg=what)
+        np.testing.assert_allclose(_np(st.action_log_dist), g["act_logdist"], rtol=1e-5, atol=5e-6, err_msg=what)
+        np.testing.assert_allclose(_np(st.recurrent_hidden_states[1]), g["hidden1"], rtol=1e-5, atol=5e-6, err_msg=what)
+        np.testing.assert_allclose(_np(st.recurrent_hidden_states[T]), g["hiddenT"], rtol=1e-5, atol=5e-6, err_msg=what)
+        a = st.actions[..., 0]
+        assert int(a.min()) >= 0 and int(a.max()) <= 6
+        assert torch.equal(st.action_log_probs, st.action_log_dist.gather(-1, st.actions))
+    check(sts[0], "StudentActor")
+    np.testing.assert_allclose(_np(fa.value_storage(sts[0], T)), g["next_value"], rtol=1e-5, atol=5e-6)
+    buf = PairedStudentActors.buffers(nets, B)
+    actors = [StudentActor(n, B, seed=5 + k, buffers=PairedStudentActors.half(buf, k)) for k, n in enumerate(nets)]
+    pair = PairedStudentActors(actors, buf)
+    sts[0].value_preds.zero_(); sts[0].action_log_dist.zero_(); sts[0].recurrent_hidden_states[1:].zero_()
+    for a in actors:
+        a.begin_rollout(T)
+    for t in range(T):
+        pair.act_storage(sts, t)
+    torch.cuda.synchronize()
+    check(sts[0], "PairedStudentActors[0]")
+    check(sts[1], "PairedStudentActors[1]")
+
+
+# ---- the teacher ------------------------------------------------------------------------------------------------------------
+def test_teacher_rollout_step_matches_reference_tape():
+    """Module path (`net.act` on device: dense 21 692-wide operand) and the fused path (`GridActor.act_storage`: carried
+    projection — dcd_grid_delta_rows + fp32 MFMA tile product + dcd_gather_sum_rows — rest operand, one GEMM,
+    dcd_policy_wide_cell_heads) over the reference's constructive tape."""
+    from dcd_hip.policy import GridActor
+    g = F.load("ppo_teacher.npz")
+    net, _ = F.teacher_net(DEV)
+    T, B = int(g["T"]), int(g["B"])
+    st = F.teacher_storage(net, g, DEV, u8=True)
+    h = st.recurrent_hidden_states[0]
+    for t in range(T):
+        with torch.no_grad():
+            v, a, ld, hc = net.act(st.get_obs(t), (h[:, :256], h[:, 256:]), st.masks[t], deterministic=True)
+        np.testing.assert_allclose(_np(v), g["act_values"][t], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(_np(ld), g["act_logdist"][t], rtol=1e-5, atol=2e-6)
+        h = torch.cat(hc, -1)
+    np.testing.assert_allclose(_np(h), g["hiddenT"], rtol=1e-5, atol=5e-6)
+    ga = GridActor.try_create(net, B)
+    assert ga is not None and ga.fused_heads and ga.device_carry_supported(st.obs_u8["image"][0])
+    st.value_preds.zero_(); st.action_log_dist.zero_(); st.recurrent_hidden_states[1:].zero_()
+    ga.begin_rollout(T)
+    ga.begin_episode()
+    for t in range(T):
+        ga.act_storage(st, t)
+    ga.check_carry_errors()
+    np.testing.assert_allclose(_np(st.value_preds[:-1]), g["act_values"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(_np(st.action_log_dist), g["act_logdist"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(_np(st.recurrent_hidden_states[1]), g["hidden1"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(_np(st.recurrent_hidden_states[T]), g["hiddenT"], rtol=1e-5, atol=5e-6)
+    assert int(st.actions.min()) >= 0 and int(st.actions.max()) < 169
+    assert torch.equal(st.action_log_probs, st.action_log_dist.gather(-1, st.actions))
+
+
+@pytest.mark.parametrize("mode", ["carried_u8", "carried_f32", "dense"])
+def test_teacher_ppo_update_on_device_matches_reference(mode, monkeypatch):
+    from algos import ACAgent
+    if mode == "dense":
+        monkeypatch.setenv("DCD_INCREMENTAL_PROJECTION", "0")
+    g = F.load("ppo_teacher.npz")
+    net, w0 = F.teacher_net(DEV)
+    st = F.teacher_storage(net, g, DEV, u8=(mode == "carried_u8"))
+    took = {"n": 0}
+    orig = net._incremental_projection
+
+    def spy(image, N):
+        out = orig(image, N)
+        took["n"] += out is not None
+        return out
+    monkeypatch.setattr(net, "_incremental_projection", spy)
+    torch.manual_seed(6)
+    vl, al, ent, info = ACAgent(_ppo(net), st).update()
+    assert took["n"] == (0 if mode == "dense" else 2)                 # both epochs went through the carried projection
+    worst = F.check_update(net, g, vl, al, ent, info, atol_w=2e-6, w0=w0, atol_action=2e-7)
+    print(f"teacher {mode}: losses {vl:.6g} {al:.6g} {ent:.6g} (ref {float(g['ppo_value_loss']):.6g} {float(g['ppo_action_loss']):.6g} "
+          f"{float(g['ppo_entropy']):.6g}); grad norms {info['grad_norms']} (ref {g['ppo_grad_norms']}); max |w - w_ref| = {worst:.3g}")

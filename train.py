@@ -86,8 +86,19 @@ def main():
         runner.agents["agent"].algo.actor_critic.load_state_dict(sd["agent_state_dict"]["agent"])
         runner.agents["agent"].algo.optimizer.load_state_dict(sd["optimizer_state_dict"]["agent"])
     idx_at_start = getattr(runner, args.checkpoint_basis)
-    t0 = timeit.default_timer()
+    t0 = t_start = timeit.default_timer()
     for j in range(runner.num_updates, num_updates):
+        if args.wall_limit_s > 0:
+            # (this engine's addition) a job with a wall-clock budget: checkpoint and leave; `--checkpoint true` resumes it.
+            # Rank 0's clock decides for every rank (one small broadcast per update, only when the flag is set)
+            over = timeit.default_timer() - t_start > args.wall_limit_s
+            if world > 1:
+                over = bool(D.broadcast_ints([int(over)], 1, group=pg, device=device)[0])
+            if over:
+                checkpoint(getattr(runner, args.checkpoint_basis))
+                if rank == 0:
+                    print(json.dumps({"wall_limit_reached_at_update": j}), flush=True)
+                break
         stats = D.reduce_stats(runner.run())
         if runner.num_updates <= last_logged_at_restart:   # train.py:165-166: neither logged, checkpointed nor screenshot again
             continue
