@@ -370,10 +370,37 @@ def _roll_and_update(net, st, agent, tape, T, masks, bad, rewards, out, seeds=(1
                hidden1=st.recurrent_hidden_states[1].numpy().copy(), hiddenT=st.recurrent_hidden_states[T].numpy().copy())
     if st.truncated_value_preds is not None:
         out["truncated_value_preds"] = st.truncated_value_preds.numpy().copy()
+    agent64 = _as_double(agent)
     torch.manual_seed(seeds[1])
     vl, al, ent, info = agent.update()
     out.update(ppo_value_loss=np.array(vl), ppo_action_loss=np.array(al), ppo_entropy=np.array(ent),
                ppo_grad_norms=np.array(info["grad_norms"]))
+    # the SAME update by the same reference code evaluated in float64 (same inputs: the fp32 rollout above, cast): what the
+    # expressions of ppo.py:61-146 give without fp32 round-off.  The reference's own fp32 CPU run sits up to 8e-4 (gradient
+    # norm of the 22.5 M-parameter teacher) away from it; the device path is compared with both.
+    torch.manual_seed(seeds[1])
+    vl, al, ent, info = agent64.update()
+    out.update(f64_ppo_value_loss=np.array(vl), f64_ppo_action_loss=np.array(al), f64_ppo_entropy=np.array(ent),
+               f64_ppo_grad_norms=np.array(info["grad_norms"]))
+    return agent64
+
+
+def _as_double(agent):
+    """A deep copy of a reference ACAgent (network, PPO with its optimiser, RolloutStorage) cast to float64.  The reference's
+    `one_hot` returns float32 (models/common.py:211-213): a forward pre-hook on the embedding that consumes it casts its input
+    to the weights' dtype — the reference's functions themselves are untouched."""
+    import copy
+    a = copy.deepcopy(agent)
+    net = a.algo.actor_critic
+    net.double()
+    net.scalar_embed.register_forward_pre_hook(lambda m, inp: (inp[0].to(m.weight.dtype),))
+    st = a.storage
+    for name, val in list(vars(st).items()):
+        if isinstance(val, torch.Tensor) and val.dtype == torch.float32:
+            setattr(st, name, val.double())
+        elif isinstance(val, dict):
+            setattr(st, name, {k: (v.double() if isinstance(v, torch.Tensor) and v.dtype == torch.float32 else v) for k, v in val.items()})
+    return a
 
 
 def gen_ppo_wide():
@@ -409,11 +436,13 @@ def gen_ppo_wide():
     st.truncated_obs["direction"].copy_(torch.from_numpy(trunc_dir8.astype(np.float32))[..., None])
     tape = lambda t: {"image": f32(img8[t]), "direction": torch.from_numpy(dir8[t].astype(np.float32))[:, None]}
     out = dict(img8=img8, dir8=dir8, trunc_img8=trunc_img8, trunc_dir8=trunc_dir8, T=np.array(T), B=np.array(B))
-    _roll_and_update(net, st, agent, tape, T, masks, bad, rewards, out)
+    a64 = _roll_and_update(net, st, agent, tape, T, masks, bad, rewards, out)
     for k, v in net.state_dict().items():
         out[f"w_after_{k}"] = v.detach().numpy().copy()
+    for k, v in a64.algo.actor_critic.state_dict().items():
+        out[f"f64_w_after_{k}"] = v.detach().numpy().astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "ppo_wide.npz"), **out)
-    print("ppo_wide.npz", len(out), "grad norms", out["ppo_grad_norms"])
+    print("ppo_wide.npz", len(out), "grad norms", out["ppo_grad_norms"], "float64:", out["f64_ppo_grad_norms"], out["ppo_value_loss"], out["f64_ppo_value_loss"])
 
 
 def gen_ppo_teacher():
@@ -450,22 +479,24 @@ def gen_ppo_teacher():
     st = RolloutStorage(net, T, B, adv_space, Discrete(169), 256, recurrent_arch="lstm", use_proper_time_limits=False)
     agent = ACAgent(algo, st)
     out = dict(enc=enc, loc=loc, random_z=z, T=np.array(T), B=np.array(B))
-    _roll_and_update(net, st, agent, tape, T, masks, bad, rewards, out, seeds=(4, 6))
+    a64 = _roll_and_update(net, st, agent, tape, T, masks, bad, rewards, out, seeds=(4, 6))
     big = "rnn.rnn.weight_ih_l0"
     cols = np.concatenate([np.arange(0, 21632, 89), np.arange(21632, 21692)])
-    for k, v in net.state_dict().items():
-        v = v.detach().numpy()
-        if k == big:
-            d = v.astype(np.float64) - w0[k].astype(np.float64)
-            out["big_cols"] = cols
-            out["w_after_big_sample"] = v[:, cols].copy()
-            out["big_delta_rowsum"] = d.sum(1)
-            out["big_delta_colsum"] = d.sum(0)
-            out["big_delta_abs_mean"] = np.array(np.abs(d).mean())
-        else:
-            out[f"w_after_{k}"] = v.copy()
+    out["big_cols"] = cols
+    for pre, sd in (("", net.state_dict()), ("f64_", a64.algo.actor_critic.state_dict())):
+        for k, v in sd.items():
+            v = v.detach().numpy()
+            if k == big:
+                d = v.astype(np.float64) - w0[k].astype(np.float64)
+                out[pre + "w_after_big_sample"] = v[:, cols].astype(np.float32)
+                out[pre + "big_delta_rowsum"] = d.sum(1)
+                out[pre + "big_delta_colsum"] = d.sum(0)
+                out[pre + "big_delta_abs_mean"] = np.array(np.abs(d).mean())
+            else:
+                out[f"{pre}w_after_{k}"] = v.astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "ppo_teacher.npz"), **out)
     print("ppo_teacher.npz", len(out), "losses", out["ppo_value_loss"], out["ppo_action_loss"], out["ppo_entropy"], "grad norms", out["ppo_grad_norms"])
+    print("   float64:", out["f64_ppo_value_loss"], out["f64_ppo_action_loss"], out["f64_ppo_entropy"], out["f64_ppo_grad_norms"])
 
 
 def gen_entropy():

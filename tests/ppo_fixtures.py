@@ -125,27 +125,28 @@ def teacher_storage(net, g, device, u8):
     return st
 
 
-def check_update(net, g, vl, al, ent, info, atol_w, w0=None, rtol_loss=1e-4, atol_action=1e-7):
-    """The reference's losses / gradient norms / post-update weights (ppo.py:61-146).  Returns the largest weight deviation."""
-    np.testing.assert_allclose(vl, g["ppo_value_loss"], rtol=rtol_loss)
-    np.testing.assert_allclose(al, g["ppo_action_loss"], rtol=rtol_loss, atol=atol_action)
-    np.testing.assert_allclose(ent, g["ppo_entropy"], rtol=rtol_loss)
-    np.testing.assert_allclose(info["grad_norms"], g["ppo_grad_norms"], rtol=1e-3)
+def check_update(net, g, vl, al, ent, info, atol_w, w0=None, rtol_loss=1e-4, atol_action=1e-7, rtol_norm=1e-3, pre=""):
+    """The reference's losses / gradient norms / post-update weights (ppo.py:61-146).  pre="": its fp32 CPU run; pre="f64_": the
+    same reference code evaluated in float64 (make_golden._as_double).  Returns the largest weight deviation."""
+    np.testing.assert_allclose(vl, g[pre + "ppo_value_loss"], rtol=rtol_loss)
+    np.testing.assert_allclose(al, g[pre + "ppo_action_loss"], rtol=rtol_loss, atol=atol_action)
+    np.testing.assert_allclose(ent, g[pre + "ppo_entropy"], rtol=rtol_loss)
+    np.testing.assert_allclose(info["grad_norms"], g[pre + "ppo_grad_norms"], rtol=rtol_norm)
     worst = 0.0
     for k, v in net.state_dict().items():
         v = v.detach().cpu().numpy()
-        if "w_after_" + k in g.files:
-            ref = g["w_after_" + k]
+        if pre + "w_after_" + k in g.files:
+            ref = g[pre + "w_after_" + k]
             worst = max(worst, float(np.abs(v - ref).max()))
             np.testing.assert_allclose(v, ref, rtol=0, atol=atol_w, err_msg=k)
         else:                               # the teacher's LSTM input weight: column sample + fp64 sums of its change
             cols = g["big_cols"]
-            worst = max(worst, float(np.abs(v[:, cols] - g["w_after_big_sample"]).max()))
-            np.testing.assert_allclose(v[:, cols], g["w_after_big_sample"], rtol=0, atol=atol_w, err_msg=k + " (column sample)")
+            worst = max(worst, float(np.abs(v[:, cols] - g[pre + "w_after_big_sample"]).max()))
+            np.testing.assert_allclose(v[:, cols], g[pre + "w_after_big_sample"], rtol=0, atol=atol_w, err_msg=k + " (column sample)")
             d = v.astype(np.float64) - w0[k].astype(np.float64)
-            scale = float(g["big_delta_abs_mean"])
+            scale = float(g[pre + "big_delta_abs_mean"])
             # a row sums 21 692 changes of mean size `scale`, a column 1 024: deviations allowed at 1e-3 of the summed magnitude
-            np.testing.assert_allclose(d.sum(1), g["big_delta_rowsum"], rtol=0, atol=1e-3 * scale * d.shape[1], err_msg=k + " (row sums)")
-            np.testing.assert_allclose(d.sum(0), g["big_delta_colsum"], rtol=0, atol=1e-3 * scale * d.shape[0], err_msg=k + " (column sums)")
+            np.testing.assert_allclose(d.sum(1), g[pre + "big_delta_rowsum"], rtol=0, atol=1e-3 * scale * d.shape[1], err_msg=k + " (row sums)")
+            np.testing.assert_allclose(d.sum(0), g[pre + "big_delta_colsum"], rtol=0, atol=1e-3 * scale * d.shape[0], err_msg=k + " (column sums)")
             np.testing.assert_allclose(np.abs(d).mean(), scale, rtol=1e-3)
     return worst

@@ -17,10 +17,18 @@ partial sums, wave reductions; hardware exp / rcp in the rollout-time activation
   the same through the fused rollout kernels                    atol 5e-6 (3e-6 against the module on one step; here
                                                                  the recurrent state is the kernels' own over the whole tape)
   truncated value predictions                                   rtol 1e-5, atol 2e-6
-  PPO losses                                                    rtol 1e-4 (north_star's "stated fp32 tolerance")
+  PPO losses                                                    rtol 1e-4 (north_star's "stated fp32 tolerance"); teacher 2e-4 (*)
   gradient norms                                                rtol 1e-3
   weights after the update (2 epochs x Adam, lr 1e-4)           atol 2e-6 = 2 % of one Adam step; the largest deviation seen
                                                                  is printed (run with -s)
+  the same quantities against the reference code in FLOAT64     losses / gradient norms rtol 1e-5, weights atol 5e-7
+
+(*) The reference's fp32 CPU run of the teacher update is itself 6.7e-4 (gradient norm) / 1.07e-4 (value loss) away from the same
+reference code evaluated in float64 (fixture keys `f64_*`): torch's CPU `norm()` accumulates the squares of the 22.2 M-element
+LSTM input gradient in fp32, so the logged norm AND the clipping factor `max_grad_norm / (norm + 1e-6)` (ppo.py:120-127) carry
+that error uniformly into every parameter's step (measured: every tensor's clipped gradient is off by the same 6.67e-4).  The
+device's tree reductions do not: the GPU results sit within 2e-7 of the float64 evaluation, i.e. closer to the reference's
+algorithm than the reference's own CPU fp32 arithmetic.  Both comparisons are asserted.
 """
 import os
 
@@ -130,6 +138,8 @@ def test_student_wide_update_through_splitk_matches_reference(u8, low_splitk_thr
     vl, al, ent, info = ACAgent(_ppo(net, num_mini_batch=2), st).update()
     assert low_splitk_threshold["tn"] >= 4 * 3                       # per minibatch: conv, LSTM input, dW_hh (+ heads) went split-K
     worst = F.check_update(net, g, vl, al, ent, info, atol_w=2e-6)
+    w64 = F.check_update(net, g, vl, al, ent, info, atol_w=5e-7, rtol_loss=1e-5, atol_action=1e-8, rtol_norm=1e-5, pre="f64_")
+    print(f"student wide u8={u8}: vs float64 reference max |w - w_ref| = {w64:.3g}")
     print(f"student wide u8={u8}: losses {vl:.6g} {al:.6g} {ent:.6g}; split-K contractions {low_splitk_threshold['tn']}; "
           f"max |w - w_ref| = {worst:.3g}")
 
@@ -227,6 +237,8 @@ def test_teacher_ppo_update_on_device_matches_reference(mode, monkeypatch):
     torch.manual_seed(6)
     vl, al, ent, info = ACAgent(_ppo(net), st).update()
     assert took["n"] == (0 if mode == "dense" else 2)                 # both epochs went through the carried projection
-    worst = F.check_update(net, g, vl, al, ent, info, atol_w=2e-6, w0=w0, atol_action=2e-7)
+    worst = F.check_update(net, g, vl, al, ent, info, atol_w=2e-6, w0=w0, rtol_loss=2e-4, atol_action=2e-7)
+    w64 = F.check_update(net, g, vl, al, ent, info, atol_w=5e-7, w0=w0, rtol_loss=1e-5, atol_action=1e-8, rtol_norm=1e-5, pre="f64_")
+    print(f"teacher {mode}: vs float64 reference max |w - w_ref| = {w64:.3g}")
     print(f"teacher {mode}: losses {vl:.6g} {al:.6g} {ent:.6g} (ref {float(g['ppo_value_loss']):.6g} {float(g['ppo_action_loss']):.6g} "
           f"{float(g['ppo_entropy']):.6g}); grad norms {info['grad_norms']} (ref {g['ppo_grad_norms']}); max |w - w_ref| = {worst:.3g}")
