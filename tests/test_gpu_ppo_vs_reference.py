@@ -22,6 +22,8 @@ partial sums, wave reductions; hardware exp / rcp in the rollout-time activation
   weights after the update (2 epochs x Adam, lr 1e-4)           atol 2e-6 = 2 % of one Adam step; the largest deviation seen
                                                                  is printed (run with -s)
   the same quantities against the reference code in FLOAT64     losses / gradient norms rtol 1e-5, weights atol 5e-7
+  (the action loss is a mean of O(1) terms that cancel to ~1e-5 .. 1e-4 — normalised advantages at ratio ~ 1 — so it carries an
+   ABSOLUTE fp32 error of ~3e-8 whatever the path: atol 2e-7 everywhere)
 
 (*) The reference's fp32 CPU run of the teacher update is itself 6.7e-4 (gradient norm) / 1.07e-4 (value loss) away from the same
 reference code evaluated in float64 (fixture keys `f64_*`): torch's CPU `norm()` accumulates the squares of the 22.2 M-element
@@ -138,7 +140,7 @@ def test_student_wide_update_through_splitk_matches_reference(u8, low_splitk_thr
     vl, al, ent, info = ACAgent(_ppo(net, num_mini_batch=2), st).update()
     assert low_splitk_threshold["tn"] >= 4 * 3                       # per minibatch: conv, LSTM input, dW_hh (+ heads) went split-K
     worst = F.check_update(net, g, vl, al, ent, info, atol_w=2e-6)
-    w64 = F.check_update(net, g, vl, al, ent, info, atol_w=5e-7, rtol_loss=1e-5, atol_action=1e-8, rtol_norm=1e-5, pre="f64_")
+    w64 = F.check_update(net, g, vl, al, ent, info, atol_w=5e-7, rtol_loss=1e-5, atol_action=2e-7, rtol_norm=1e-5, pre="f64_")
     print(f"student wide u8={u8}: vs float64 reference max |w - w_ref| = {w64:.3g}")
     print(f"student wide u8={u8}: losses {vl:.6g} {al:.6g} {ent:.6g}; split-K contractions {low_splitk_threshold['tn']}; "
           f"max |w - w_ref| = {worst:.3g}")
@@ -238,7 +240,7 @@ def test_teacher_ppo_update_on_device_matches_reference(mode, monkeypatch):
     vl, al, ent, info = ACAgent(_ppo(net), st).update()
     assert took["n"] == (0 if mode == "dense" else 2)                 # both epochs went through the carried projection
     worst = F.check_update(net, g, vl, al, ent, info, atol_w=2e-6, w0=w0, rtol_loss=2e-4, atol_action=2e-7)
-    w64 = F.check_update(net, g, vl, al, ent, info, atol_w=5e-7, w0=w0, rtol_loss=1e-5, atol_action=1e-8, rtol_norm=1e-5, pre="f64_")
+    w64 = F.check_update(net, g, vl, al, ent, info, atol_w=5e-7, w0=w0, rtol_loss=1e-5, atol_action=2e-7, rtol_norm=1e-5, pre="f64_")
     print(f"teacher {mode}: vs float64 reference max |w - w_ref| = {w64:.3g}")
     print(f"teacher {mode}: losses {vl:.6g} {al:.6g} {ent:.6g} (ref {float(g['ppo_value_loss']):.6g} {float(g['ppo_action_loss']):.6g} "
           f"{float(g['ppo_entropy']):.6g}); grad norms {info['grad_norms']} (ref {g['ppo_grad_norms']}); max |w - w_ref| = {worst:.3g}")
