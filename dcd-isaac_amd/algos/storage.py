@@ -26,6 +26,33 @@ def _flatten(T, N, x):
     return x.reshape(T * N, *x.shape[2:])
 
 
+class LazyU8Obs(dict):
+    """A PPO minibatch's student observations as the RAW bytes the rollout buffers hold (`image_u8` [R,V,V,3], `direction_u8` [R]):
+    the fused feature kernel (models/fused_ppo.py) reads them directly — a quarter of the gather and no conversion pass.  The
+    fp32 entries the reference's API exposes (`image` [R,3,V,V] = bytes / 10 in CHW, `direction` [R,1]; obs_wrappers.py:88-115)
+    are materialised on first access by dcd_obs_u8_to_f32, bit-identical to the engine's own fp32 emission."""
+
+    def __init__(self, image_u8, direction_u8, convert):
+        super().__init__(image_u8=image_u8, direction_u8=direction_u8)
+        self._convert = convert
+
+    def __missing__(self, key):
+        if key not in ("image", "direction"):
+            raise KeyError(key)
+        img8 = self["image_u8"]
+        dst = {"image": torch.empty((img8.shape[0], 3, img8.shape[1], img8.shape[2]), device=img8.device),
+               "direction": torch.empty((img8.shape[0], 1), device=img8.device)}
+        self._convert({"image": img8, "direction": self["direction_u8"]}, dst, slice(None))
+        dict.update(self, dst)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+
 class RolloutStorage:
     def __init__(self, model, num_steps, num_processes, observation_space, action_space,
                  recurrent_hidden_state_size, recurrent_arch="rnn", use_proper_time_limits=False,
@@ -454,11 +481,17 @@ class RolloutStorage:
             idx = perm[s:s + per].to(self.device)
             N = idx.numel()
             sel = lambda x: x.index_select(1, idx)
-            obs = ({k: sel(v[:-1]) for k, v in self.obs.items()} if self.is_dict_obs else sel(self.obs[:-1]))
+            if self.obs_u8 is not None and set(self.obs_u8) == {"image", "direction"} and set(self._obs) == {"image", "direction"}:
+                # students in u8 mode: the minibatch carries the raw bytes; fp32 views on demand (LazyU8Obs)
+                i8, d8 = sel(self.obs_u8["image"][:-1]), sel(self.obs_u8["direction"][:-1])
+                obs_b = LazyU8Obs(i8.reshape(T * N, *i8.shape[2:]), d8.reshape(T * N), self._convert)
+            else:
+                obs = ({k: sel(v[:-1]) for k, v in self.obs.items()} if self.is_dict_obs else sel(self.obs[:-1]))
+                obs_b = _flatten(T, N, obs)
             hxs = self.recurrent_hidden_states[0].index_select(0, idx)
             if self.is_lstm:
                 hxs = self._split_batched_lstm_recurrent_hidden_states(hxs)
-            yield (_flatten(T, N, obs), hxs, _flatten(T, N, sel(self.actions)),
+            yield (obs_b, hxs, _flatten(T, N, sel(self.actions)),
                    _flatten(T, N, sel(self.value_preds[:-1])), _flatten(T, N, sel(self.returns[:-1])),
                    _flatten(T, N, sel(self.masks[:-1])), _flatten(T, N, sel(self.action_log_probs)),
                    _flatten(T, N, sel(advantages)))

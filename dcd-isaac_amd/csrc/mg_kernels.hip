@@ -238,15 +238,21 @@ struct StepRes { float reward, ep_ret; int ep_len; uint32_t flags; uint32_t doff
 // [bps, 2 bps) replica 1; a replica has its own action array and output set, everything else is indexed by record row.
 // OBS8: only the raw u8 observation is emitted (obs.image_u8 / dir_u8 and, for truncations, term_obs.image_u8): the fp32
 // tables of the emission are not built.
-template <bool RANDOM, int EPB, bool RR, bool PAIR = false, bool OBS8 = false>
-__global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel(const uint8_t* __restrict__ rec_in,
+// LEAN (round 4; the bandwidth regime only: EPB = 64 with raw-u8 emission): 4 waves and 19 KB of LDS per workgroup instead of
+// 6 waves and 29.6 KB, i.e. 8 resident workgroups per CU instead of 5 (both limits, 32 wave slots and 160 KB, were at 5).  The SQ
+// counters of the 6-wave kernel at 1 M envs (profiles/r04_pmc_sq_wide_step_before.json) show waves PARKED 70 % of their cycles with
+// the vector ALUs 45 % busy: the launch is short of parallel slack, not of bandwidth.  No duty waves — waves 1 and 2 take the
+// scalar outputs and the record write-back before they join the render — and no staging buffer for terminal observations: the
+// logic wave writes the (rare) pre-reset view straight to global memory.
+template <bool RANDOM, int EPB, bool RR, bool PAIR = false, bool OBS8 = false, bool LEAN = false>
+__global__ void __launch_bounds__(Threads<EPB>::value + (LEAN ? 0 : 2 * WAVE)) mg_step_kernel(const uint8_t* __restrict__ rec_in,
                                                                                  const uint32_t* __restrict__ seed_in,
                                                                                  const int64_t* __restrict__ actions_in, int B_in,
                                                                                  const int64_t* __restrict__ actions1_in,
                                                                                  Params p, StepArgs a) {
   constexpr int NT = Threads<EPB>::value;
   __shared__ __attribute__((aligned(16))) uint8_t lds[EPB * LP];
-  __shared__ __attribute__((aligned(16))) uint8_t sterm[EPB * MAX_OP];
+  __shared__ __attribute__((aligned(16))) uint8_t sterm[LEAN ? 16 : EPB * MAX_OP];
   __shared__ StepRes res[EPB];
   __shared__ uint8_t term_valid[EPB];
   __shared__ int any_term;
@@ -301,17 +307,24 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
           const int src = __builtin_ctzll(tm); tm &= tm - 1;
           const int ax = __shfl(e.ax, src), ay = __shfl(e.ay, src), ad = __shfl(e.adir, src), ca = __shfl(e.carrying, src);
           auto rec = as_lds(lds + src * LP);
-          auto out = as_lds(sterm + src * OP);
           const int vx = tid / V, vy = tid - vx * V;
           const uint8_t cc = tid < VV ? view_cell_code(rec, p.S, V, ax, ay, ad, ca, vx, vy) : C_WALL_GREY;
           unsigned long long vis = ~0ull;
           if (!p.see_through_walls)
             vis = process_vis_mask(__ballot(tid < VV && ((vx == V / 2 && vy == V - 1) || see_behind(cc))), V);
-          if (tid < VV) {
-            const uint32_t t = ((vis >> tid) & 1) ? enc3(cc) : 0u;
-            out[tid * 3] = (uint8_t)t; out[tid * 3 + 1] = (uint8_t)(t >> 8); out[tid * 3 + 2] = (uint8_t)(t >> 16);
+          const uint32_t t = (tid < VV && ((vis >> tid) & 1)) ? enc3(cc) : 0u;
+          if (LEAN) {                                                  // straight to info['truncated_obs'] (u8 emission only)
+            uint8_t* gi = outs.term_obs.image_u8;
+            if (gi && tid < VV) {
+              uint8_t* q = gi + (size_t)(env0 + src) * (VV * 3) + tid * 3;
+              q[0] = (uint8_t)t; q[1] = (uint8_t)(t >> 8); q[2] = (uint8_t)(t >> 16);
+            }
+            if (tid == 0 && outs.term_obs.dir_u8) outs.term_obs.dir_u8[env0 + src] = (uint8_t)ad;
+          } else {
+            auto out = as_lds(sterm + src * OP);
+            if (tid < VV) { out[tid * 3] = (uint8_t)t; out[tid * 3 + 1] = (uint8_t)(t >> 8); out[tid * 3 + 2] = (uint8_t)(t >> 16); }
+            if (tid == 0) out[VV * 3] = (uint8_t)ad;
           }
-          if (tid == 0) out[VV * 3] = (uint8_t)ad;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       }
@@ -321,7 +334,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
       }
     }
     if (live) {
-      if (DCD_RARE(r.have_term)) { term_valid[tid] = 1; any_term = 1; }
+      if (!LEAN && DCD_RARE(r.have_term)) { term_valid[tid] = 1; any_term = 1; }
       e.store_dyn();                                 // LDS copy feeds the render and the write-back wave
       StepRes sr;
       sr.reward = r.reward; sr.ep_ret = r.ep_ret; sr.ep_len = r.ep_len;
@@ -335,13 +348,8 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
   }
   __syncthreads();
   STAMP(4);
-  if (tid < NT) {
-    render_emit_v<EPB, NT>(lds, lut, outs.obs, (size_t)env0, n, p, tid);      // post-auto-reset observation
-    STAMP(5);
-    if (any_term) emit_staged<NT>(sterm, lut, outs.term_obs, (size_t)env0, n, p.V, tid, term_valid);
-    STAMP(6);
-  } else if (tid < NT + WAVE) {                      // duty wave A: per-env scalar outputs
-    const int l = tid - NT, ev = env0 + l;
+  auto duty_scalars = [&](int l) {                    // per-env scalar outputs
+    const int ev = env0 + l;
     if (l < n) {
       const StepRes sr = res[l];
       const uint32_t done = sr.flags & 255, info = (sr.flags >> 8) & 255;
@@ -355,8 +363,8 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
       if (o.bad_masks) st_out<(EPB == 64)>(&o.bad_masks[ev], (info & DCD_INFO_TRUNC_KEY) ? 0.f : 1.f);
       if (o.cliffhanger_masks) st_out<(EPB == 64)>(&o.cliffhanger_masks[ev], (info & DCD_INFO_CLIFFHANGER) ? 0.f : 1.f);
     }
-  } else {                                           // duty wave B: record write-back
-    const int l = tid - NT - WAVE;
+  };
+  auto duty_writeback = [&](int l) {                  // record write-back
     if (l < n) {
       const StepRes sr = res[l];
       uint8_t* g = a.rec + (size_t)(row0 + l) * REC_BYTES;
@@ -380,6 +388,20 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
         st_out<(EPB == 64)>(reinterpret_cast<u32x4*>(g + DYN), u32x4{dyn.x, dyn.y, dyn.z, dyn.w});
       }
     }
+  };
+  if (LEAN) {                                          // waves 1 and 2 issue the duty stores, then every wave renders
+    if (tid >= WAVE && tid < 2 * WAVE) duty_scalars(tid - WAVE);
+    else if (tid >= 2 * WAVE && tid < 3 * WAVE) duty_writeback(tid - 2 * WAVE);
+    render_emit_v<EPB, NT>(lds, lut, outs.obs, (size_t)env0, n, p, tid);
+  } else if (tid < NT) {
+    render_emit_v<EPB, NT>(lds, lut, outs.obs, (size_t)env0, n, p, tid);      // post-auto-reset observation
+    STAMP(5);
+    if (any_term) emit_staged<NT>(sterm, lut, outs.term_obs, (size_t)env0, n, p.V, tid, term_valid);
+    STAMP(6);
+  } else if (tid < NT + WAVE) {                      // duty wave A
+    duty_scalars(tid - NT);
+  } else {                                           // duty wave B
+    duty_writeback(tid - NT - WAVE);
   }
   if (RANDOM && a.n_episodes && tid < WAVE) {
     for (int off = 32; off > 0; off >>= 1) episodes += __shfl_down(episodes, off);
@@ -887,7 +909,8 @@ static int launch_step(DcdMg* h, int n_sets, const int64_t* actions0, const int6
   else dcd::prof_pair(dcd::PROF_STEP, &e0, &e1);
   const int epb = step_epb(h->p.B * n_sets);
   const dim3 grid(((h->p.B + epb - 1) / epb) * n_sets);
-#define DCD_LAUNCH_STEP(EPB_, RR_, PAIR_, O8_) hipExtLaunchKernelGGL((mg_step_kernel<false, EPB_, RR_, PAIR_, O8_>), grid, dim3(Threads<EPB_>::value + 2 * WAVE), 0, (hipStream_t)stream, e0, e1, 0, (const uint8_t*)h->rec, (const uint32_t*)h->seed, actions0, h->p.B, actions1, h->p, a)
+#define DCD_LAUNCH_STEP_L(EPB_, RR_, PAIR_, O8_, LEAN_) hipExtLaunchKernelGGL((mg_step_kernel<false, EPB_, RR_, PAIR_, O8_, LEAN_>), grid, dim3(Threads<EPB_>::value + (LEAN_ ? 0 : 2 * WAVE)), 0, (hipStream_t)stream, e0, e1, 0, (const uint8_t*)h->rec, (const uint32_t*)h->seed, actions0, h->p.B, actions1, h->p, a)
+#define DCD_LAUNCH_STEP(EPB_, RR_, PAIR_, O8_) DCD_LAUNCH_STEP_L(EPB_, RR_, PAIR_, O8_, false)
 #define DCD_LAUNCH_RR(EPB_, PAIR_, O8_) do { if (rr) DCD_LAUNCH_STEP(EPB_, true, PAIR_, O8_); else DCD_LAUNCH_STEP(EPB_, false, PAIR_, O8_); } while (0)
 #define DCD_LAUNCH_EPB(EPB_) do { if (n_sets == 2) { if (obs8) DCD_LAUNCH_RR(EPB_, true, true); else DCD_LAUNCH_RR(EPB_, true, false); } \
                                   else { if (obs8) DCD_LAUNCH_RR(EPB_, false, true); else DCD_LAUNCH_RR(EPB_, false, false); } } while (0)
@@ -895,8 +918,14 @@ static int launch_step(DcdMg* h, int n_sets, const int64_t* actions0, const int6
   // raw-u8-only emission: no set wants an fp32 image
   auto u8_only = [&](const DcdStepOut& o) { return o.obs.image_u8 && !o.obs.image_f32 && !o.term_obs.image_f32; };
   const bool obs8 = u8_only(a.out[0]) && (n_sets == 1 || u8_only(a.out[1]));
-  if (epb == 16) DCD_LAUNCH_EPB(16); else if (epb == 32) DCD_LAUNCH_EPB(32); else DCD_LAUNCH_EPB(64);
+  static const bool lean_ok = []() { const char* v = getenv("DCD_WIDE_LEAN"); return !(v && v[0] == '0'); }();
+  if (epb == 16) DCD_LAUNCH_EPB(16); else if (epb == 32) DCD_LAUNCH_EPB(32);
+  else if (obs8 && lean_ok) {                          // bandwidth regime, raw-u8 emission: the 4-wave workgroup
+    if (n_sets == 2) { if (rr) DCD_LAUNCH_STEP_L(64, true, true, true, true); else DCD_LAUNCH_STEP_L(64, false, true, true, true); }
+    else { if (rr) DCD_LAUNCH_STEP_L(64, true, false, true, true); else DCD_LAUNCH_STEP_L(64, false, false, true, true); }
+  } else DCD_LAUNCH_EPB(64);
 #undef DCD_LAUNCH_EPB
+#undef DCD_LAUNCH_STEP_L
 #undef DCD_LAUNCH_RR
 #undef DCD_LAUNCH_STEP
   HIP_OK(hipGetLastError());

@@ -201,7 +201,23 @@ class MultigridNetwork(DeviceAwareModule):
         feats, _ = self._forward_base(inputs, rnn_hxs, masks)
         return self.critic(feats)
 
+    def _fused_ppo_eligible(self, inputs, rnn_hxs, action):
+        """The PPO batch of the registered student on the device: features / heads as fused HIP kernels (models/fused_ppo.py)."""
+        from . import fused_ppo
+        ok = getattr(self, "_fused_ppo_supported", None)
+        if ok is None:
+            ok = self._fused_ppo_supported = fused_ppo.supported(self)
+        if not ok or not fused_ppo.enabled() or not isinstance(rnn_hxs, (tuple, list)) or action.dtype != torch.int64:
+            return False
+        image = inputs["image_u8"] if "image_u8" in inputs else inputs.get("image")
+        n_state = rnn_hxs[0].size(0)
+        return (image is not None and image.is_cuda and image.dim() == 4 and n_state > 0 and image.size(0) % n_state == 0
+                and self.image_conv[0].weight.is_cuda)
+
     def evaluate_actions(self, inputs, rnn_hxs, masks, action):
+        if self._fused_ppo_eligible(inputs, rnn_hxs, action):
+            from . import fused_ppo
+            return fused_ppo.evaluate_actions(self, inputs, rnn_hxs, masks, action)
         feats, rnn_hxs = self._forward_base(inputs, rnn_hxs, masks)
         dist = self.actor(feats)
         return self.critic(feats), dist.log_probs(action), dist.entropy().mean(), rnn_hxs

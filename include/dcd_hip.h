@@ -516,6 +516,40 @@ int dcd_lstm_seq_bwd_step(const float* act, const float* c_t, const float* c_pre
                           const float* dh_last, const float* dc_last, float* dgates, float* dcf, int32_t N,
                           int32_t H, void* stream);
 
+/* ---- the student's PPO batch: features and heads as fused kernels (csrc/ppo_kernels.hip) --------------------------
+ * `PPO.update` (algos/ppo.py:83-116) calls `evaluate_actions` (models/multigrid_models.py:169-186) on T*B rows per
+ * minibatch.  Around the LSTM and the dense contractions (which stay GEMMs issued by the caller) the rest of that
+ * forward / backward pass runs in these four kernels; the registered student only (5 x 5 view, Conv 3 -> 16,
+ * embedding up to 8 x 8, 32-unit head layers, at most 8 actions), anything else is refused.
+ *   features_fwd  x float[R,x_pitch]: [relu(conv(image)) flattened [16][3][3] | scalar_embed(one_hot(direction)) | 1 | 0..]
+ *                 (multigrid_models.py:109-131; x_pitch >= 144 + E + 1: the 1 multiplies the bias column the caller
+ *                 stacks onto W_ih).  obs_u8 = 0: image float[R,3,5,5] (CHW, bytes / 10), direction float[R];
+ *                 obs_u8 = 1: image uint8[R,5,5,3], direction uint8[R] (the rollout buffers' raw bytes; / 10 and
+ *                 HWC->CHW of obs_wrappers.py:88-115 applied while staging).
+ *   features_bwd  from dx float[R,x_pitch] and the saved x (its own ReLU mask): partial float[n_wg, 512] with n_wg =
+ *                 ceil(R / rows_per_wg) (rows_per_wg a multiple of 16), row layout [0,432) d conv.weight [f][c][ky][kx] |
+ *                 [432,448) d conv.bias | 448 + 8 j + d: d scalar_embed.weight[j][d]; the caller adds the rows up
+ *                 (d scalar_embed.bias[j] = sum over d).
+ *   heads_fwd     pre_act float[R,64] = h @ [actor.0.0.weight ; critic.0.0.weight]^T (no bias) in, tanh(. + bias) out
+ *                 (kept for the backward); actions int64[R]; logp_all float[R,8] (normalised logits, FixedCategorical,
+ *                 models/distributions.py:18-56); value float[R]; logp_act float[R] = log_prob(action); entropy float[R]
+ *                 (per row; evaluate_actions returns its mean).
+ *   heads_bwd     upstream dvalue / dlogp / dentropy float[R] (any may be NULL = 0); act_dpre: tanh outputs in, d
+ *                 pre-activations out (the caller forms dh = dpre @ W1 and dW1 = dpre^T h); partial float[n_wg, 384]
+ *                 (rows_per_wg a multiple of 128): [0,256) d actor.1.linear.weight [k][i] (k < 8) | [256,264) its bias |
+ *                 [264,296) d critic.1.weight | 296 its bias | [304,336) d actor.0.0.bias | [336,368) d critic.0.0.bias.
+ * Sums run in a fixed order (no atomics): results do not depend on scheduling. */
+int dcd_ppo_features_partial_floats(void);
+int dcd_ppo_heads_partial_floats(void);
+int dcd_ppo_features_fwd(const DcdStudentNet* net, const void* image, const void* direction, int32_t obs_u8, float* x, int32_t x_pitch,
+                         int64_t R, void* stream);
+int dcd_ppo_features_bwd(const DcdStudentNet* net, const void* image, const void* direction, int32_t obs_u8, const float* x, const float* dx,
+                         int32_t x_pitch, int64_t R, int32_t rows_per_wg, float* partial, void* stream);
+int dcd_ppo_heads_fwd(const DcdStudentNet* net, float* pre_act, const int64_t* actions, float* logp_all, float* value, float* logp_act,
+                      float* entropy, int64_t R, void* stream);
+int dcd_ppo_heads_bwd(const DcdStudentNet* net, float* act_dpre, const float* logp_all, const int64_t* actions, const float* dvalue,
+                      const float* dlogp, const float* dentropy, int64_t R, int32_t rows_per_wg, float* partial, void* stream);
+
 /* Scatter side of the teacher's incremental input projection (no reference counterpart: the reference multiplies the
  * dense 21 632-wide conv features every step, models/multigrid_models.py:122-138): out[r,:] += sum_k y[src[r,k],:],
  * src int32[R,K] (negative = no term), terms added in k order; y float[*,G], out float[R,G], G a multiple of 4,

@@ -78,3 +78,25 @@ def test_new_struct_layouts_and_argument_checks_need_no_gpu():
     assert L.dcd_grid_delta_tiles(ctypes.c_int32(15), ctypes.c_int32(4096)) == (9 * 4096 + 169 * 127 + 127) // 128
     assert L.dcd_grid_delta_tiles(ctypes.c_int32(40), ctypes.c_int32(4096)) == 0       # grid too large for the carried projection
     assert L.dcd_policy_wide_packed_heads_floats(ctypes.byref(net)) == 0              # head weights not set -> refused
+
+
+def test_ppo_entry_points_refuse_unsupported_shapes_without_a_device():
+    """dcd_ppo_* (round 4) are built for the registered student only and say so before any HIP call."""
+    import dcd_hip
+    from dcd_hip.policy import StudentNet
+    L = ctypes.CDLL(dcd_hip.LIB_PATH)
+    L.dcd_last_error.restype = ctypes.c_char_p
+    assert L.dcd_ppo_features_partial_floats() == 512 and L.dcd_ppo_heads_partial_floats() == 384
+    net = StudentNet()
+    for k, v in dict(V=15, F=128, E=10, D=28, H=256, A1=32, C1=32, NA=169).items():      # the teacher's geometry
+        setattr(net, k, v)
+    one = ctypes.c_void_p(16)
+    assert L.dcd_ppo_features_fwd(ctypes.byref(net), one, one, 0, one, 152, ctypes.c_int64(4), None) != 0
+    assert b"registered student" in L.dcd_last_error()
+    assert L.dcd_ppo_heads_fwd(ctypes.byref(net), one, one, one, one, one, one, ctypes.c_int64(4), None) != 0
+    assert b"at most 8 actions" in L.dcd_last_error()
+    for k, v in dict(V=5, F=16, E=5, D=4, NA=7).items():
+        setattr(net, k, v)
+    assert L.dcd_ppo_features_fwd(ctypes.byref(net), None, one, 0, one, 152, ctypes.c_int64(4), None) != 0          # NULL image
+    assert L.dcd_ppo_features_bwd(ctypes.byref(net), one, one, 0, one, one, 152, ctypes.c_int64(4), 24, one, None) != 0  # 24 % 16
+    assert b"multiple of 16" in L.dcd_last_error()
