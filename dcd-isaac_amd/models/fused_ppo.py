@@ -22,7 +22,7 @@ import os
 
 import torch
 
-from .common import matmul_tn
+from . import common
 
 KP = 152                 # operand pitch: 144 conv features + 5 embedding + the constant 1, padded to a multiple of 8
 
@@ -128,7 +128,7 @@ class LinearOnes(torch.autograd.Function):
         K = ctx.K
         g = g.contiguous()
         dx1 = g @ w1 if ctx.needs_input_grad[0] else None
-        dw1 = matmul_tn(g, x1)
+        dw1 = common.matmul_tn(g, x1)
         return dx1, dw1[:, :K], dw1[:, K]
 
 
@@ -173,7 +173,7 @@ class StudentHeads(torch.autograd.Function):
         NA = s.NA
         dpre = act
         dh = dpre @ w1 if ctx.needs_input_grad[1] else None
-        dw1 = matmul_tn(dpre, h)                                         # [64, H]
+        dw1 = common.matmul_tn(dpre, h)                                         # [64, H]
         return (None, dh, None, dw1[:32], g[304:336], g[:256].view(8, 32)[:NA].contiguous(), g[256:256 + NA], dw1[32:], g[336:368],
                 g[264:296].view(1, 32), g[296:297])
 
