@@ -66,13 +66,18 @@ __device__ __forceinline__ void init_luts(Luts& l, int tid) {
 // ---- workgroup-cooperative record staging: n rows x 16 chunks of 16 B over NT threads ---------
 template <int ROWS, int NT>
 struct StageBuf { uint4 v[(ROWS * 16 + NT - 1) / NT]; };
-template <int ROWS, int NT, class RowToEnv>
+// MASKED (level kernels): env_of(row) < 0 marks a row the call leaves alone; the step kernel's rows are never masked and its
+// code stays what it was (the B = 4096 launch is sensitive to where its hot code falls)
+template <int ROWS, int NT, bool MASKED = false, class RowToEnv>
 __device__ __forceinline__ void stage_load(StageBuf<ROWS, NT>& sb, const uint8_t* __restrict__ rec, RowToEnv env_of, int n, int tid) {
 #pragma unroll
   for (int i = 0; i < (ROWS * 16 + NT - 1) / NT; ++i) {
     const int q = i * NT + tid, row = q >> 4, c = q & 15;
     sb.v[i] = make_uint4(0, 0, 0, 0);
-    if (row < n) sb.v[i] = *reinterpret_cast<const uint4*>(rec + (size_t)env_of(row) * REC_BYTES + c * 16);
+    if (row < n) {
+      const int ev = env_of(row);
+      if (!MASKED || ev >= 0) sb.v[i] = *reinterpret_cast<const uint4*>(rec + (size_t)ev * REC_BYTES + c * 16);
+    }
   }
 }
 template <int ROWS, int NT>
@@ -83,11 +88,12 @@ __device__ __forceinline__ void stage_commit(const StageBuf<ROWS, NT>& sb, uint8
     if (row < n) *reinterpret_cast<uint4*>(lds + row * LP + c * 16) = sb.v[i];
   }
 }
-template <int NT, class RowToEnv>
+template <int NT, bool MASKED = false, class RowToEnv>
 __device__ __forceinline__ void stage_out(const uint8_t* lds, uint8_t* __restrict__ rec, RowToEnv env_of, int n, int tid) {
   for (int q = tid; q < n * 16; q += NT) {
     const int row = q >> 4, c = q & 15;
-    *reinterpret_cast<uint4*>(rec + (size_t)env_of(row) * REC_BYTES + c * 16) = *reinterpret_cast<const uint4*>(lds + row * LP + c * 16);
+    const int ev = env_of(row);
+    if (!MASKED || ev >= 0) *reinterpret_cast<uint4*>(rec + (size_t)ev * REC_BYTES + c * 16) = *reinterpret_cast<const uint4*>(lds + row * LP + c * 16);
   }
 }
 
@@ -104,7 +110,7 @@ __device__ __forceinline__ void stage_out(const uint8_t* lds, uint8_t* __restric
 // 4.40 -> 4.58 us per launch at 8192 envs, 134 -> 144 us at 1M.)
 template <int V, int ROWS, int NT>
 __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
-                                            int n, int S, int tid, int see_through) {
+                                            int n, int S, int tid, int see_through, const int* valid = nullptr) {
   // TPE threads per env (power of two >= V*V): env = slot >> log2(TPE), view cell = slot & (TPE-1) — shifts
   // and masks instead of divisions; all offsets are 32-bit from per-workgroup base pointers.
   constexpr int VV = V * V, H = V / 2, TPE = VV <= 16 ? 16 : (VV <= 32 ? 32 : 64), ITERS = (ROWS * TPE + NT - 1) / NT;
@@ -117,7 +123,7 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
     for (int i = 0; i < ITERS; ++i) {                         // phase 1: all LDS gathers in flight together
       const int q = i * NT + tid, row = q / TPE, ci = q & (TPE - 1), vx = ci / V, vy = ci - vx * V;
       code[i] = -1;
-      if (row < n && ci < VV) {
+      if (row < n && ci < VV && (!valid || valid[row] >= 0)) {   // valid: rows of a masked level op that were left alone
         const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + row * LP + DYN);
         const int ax = dyn & 255, ay = (dyn >> 8) & 255, d = (dyn >> 16) & 255;
         const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
@@ -159,7 +165,7 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
       }
     }
   }
-  if (tid < n) {
+  if (tid < n && (!valid || valid[tid] >= 0)) {
     const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + tid * LP + DYN);
     const int d = ((dyn & 255) == NOPOS) ? 0 : ((dyn >> 16) & 255);
     if (o.dir_u8) st_out<(ROWS == 64)>(&o.dir_u8[out_row0 + tid], (uint8_t)d);
@@ -168,10 +174,10 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
 }
 template <int ROWS, int NT>
 __device__ __forceinline__ void render_emit_v(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
-                                              int n, const Params& p, int tid) {
-  if (p.V == 5) render_emit<5, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls);
-  else if (p.V == 7) render_emit<7, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls);
-  else render_emit<3, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls);
+                                              int n, const Params& p, int tid, const int* valid = nullptr) {
+  if (p.V == 5) render_emit<5, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls, valid);
+  else if (p.V == 7) render_emit<7, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls, valid);
+  else render_emit<3, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls, valid);
 }
 
 // ---- emission of per-lane staged observations (terminal obs: rare) ---------------------------
@@ -419,6 +425,8 @@ struct LevelArgs {
   const int64_t* loc;                             // OP_STEP_ADV [B]; OP_REPLAY actions [n,max_len]
   const int32_t* lens; int max_len;               // OP_REPLAY
   const uint8_t* enc;                             // OP_SET_ENCODING [n,S,S,3]
+  const int32_t* level_idx;                       // OP_SET_ENCODING / OP_REPLAY, optional [n_rows]: row r takes level level_idx[r] of enc /
+                                                  // loc / lens (a level TABLE) instead of level r; < 0: the row's env is left alone
   int num_edits;                                  // OP_MUTATE
   DcdAdvObs adv; uint8_t* adv_done;               // teacher outputs
   DcdStudentObs stu;                              // student outputs
@@ -463,21 +471,28 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
   __shared__ uint32_t bad_enc[DECODE ? EPB : 1];
   const int tid = threadIdx.x, row0 = blockIdx.x * EPB;
   const int n = min(EPB, n_rows_in - row0), row = row0 + tid;
-  if (tid < EPB) env_of[tid] = (tid < n) ? (idx_in ? idx_in[row] : row) : -1;
+  const int32_t* __restrict__ lvl = (OP == OP_SET_ENCODING || OP == OP_REPLAY) ? a.level_idx : nullptr;
+  if (tid < EPB) {
+    int ev = (tid < n) ? (idx_in ? idx_in[row] : row) : -1;
+    if (lvl && ev >= 0 && lvl[row] < 0) ev = -1;
+    env_of[tid] = ev;
+  }
   const int S = p.S;
   init_luts(lut, tid);
   if (DECODE && tid < EPB) bad_enc[tid] = 0;
   __syncthreads();
   {
     StageBuf<EPB, NT> sb;
-    stage_load<EPB, NT>(sb, rec_in, [&](int r) { return env_of[r]; }, n, tid);
+    stage_load<EPB, NT, true>(sb, rec_in, [&](int r) { return env_of[r]; }, n, tid);
     stage_commit<EPB, NT>(sb, lds, n, tid);
   }
   if (DECODE) {                                   // WorldObj.decode of every cell of every row (multigrid.py:264-280), one per thread
     const int SS = S * S;
     for (int q = tid; q < n * SS; q += NT) {
       const int r = q / SS, cell = q - r * SS;
-      const uint8_t* c = a.enc + ((size_t)(row0 + r) * SS + cell) * 3;
+      const int src = lvl ? lvl[row0 + r] : row0 + r;
+      if (src < 0) continue;
+      const uint8_t* c = a.enc + ((size_t)src * SS + cell) * 3;
       uint8_t code;
       if (!dec3(c[0], c[1], c[2], &code)) { atomicOr(&bad_enc[r], 1u); code = C_NONE; }
       codes[r * (MAX_SIZE * MAX_SIZE) + cell] = code;
@@ -486,7 +501,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
   __syncthreads();
 
   constexpr bool ADV_OUT = (OP == OP_RESET || OP == OP_STEP_ADV || OP == OP_READ_ENC);
-  if (tid < n && OP != OP_READ_ENC) {
+  if (tid < n && OP != OP_READ_ENC && env_of[tid] >= 0) {
     const int env = env_of[tid];
     // (key / metrics / teacher action are read here, after the staging barrier: issuing the three loads next to the record
     // loads at kernel entry measured 1.6 % SLOWER on the whole pass, same-box A/B, round 2)
@@ -522,10 +537,11 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
     } else if (OP == OP_REPLAY) {
       env_reset(e, p, m, nullptr);
       e.elapsed = 0;
-      const int L = a.lens[row];
+      const int src = lvl ? lvl[row] : row;
+      const int L = a.lens[src];
       if (p.resample_n_clutter) e.sb(7) = (uint8_t)L;                       // adversarial.py:277-278
       for (int k = 0; k < L; ++k)
-        if (env_step_adversary(e, p, m, a.loc[(size_t)row * a.max_len + k], nullptr)) reset_agent(e);   // :280-283
+        if (env_step_adversary(e, p, m, a.loc[(size_t)src * a.max_len + k], nullptr)) reset_agent(e);   // :280-283
     } else if (OP == OP_MUTATE) {
       env_mutate_level(e, p, m, a.num_edits);
     }
@@ -539,7 +555,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
     }
   }
   __syncthreads();
-  if (OP != OP_READ_ENC) stage_out<NT>(lds, a.rec, [&](int r) { return env_of[r]; }, n, tid);
+  if (OP != OP_READ_ENC) stage_out<NT, true>(lds, a.rec, [&](int r) { return env_of[r]; }, n, tid);
   if (ADV_OUT) {
     if (OP != OP_READ_ENC && a.adv.random_z) {
       // generate_random_z (adversarial.py:449-450): (row, q) pairs, one Philox block = 4 floats each
@@ -559,8 +575,50 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
     if (S == 15) emit_grid<15, NT>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
     else emit_grid<0, NT>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
   } else {
-    render_emit_v<EPB, NT>(lds, lut, a.stu, (size_t)row0, n, p, tid);
+    render_emit_v<EPB, NT>(lds, lut, a.stu, (size_t)row0, n, p, tid, lvl ? env_of : nullptr);
   }
+}
+
+// ---- replay rollouts: the next queued level for every env that just finished an episode ---------------------------------
+// adversarial_runner.py:551-558 re-samples a level for each finished env, in env order, between two steps — on the host in
+// the reference.  The draws are ONE sequential stream (level_sampler.py:664-680) that the host has speculated ahead
+// (LevelSampler.prefetch_next_update); its next K entries sit in `q_rows` / `q_seeds`.  One workgroup walks the batch in env
+// order: the k-th finished env of this step takes entry cursor + k; level_idx[env] = table row to reset to (-1: not finished),
+// cur_seed[env] = its new level seed, solved[env] |= 1; cursor advances by the number of finished envs.  Past the end of the
+// queue envs get -1 and *overflow is set: the caller rolls the rollout back and runs it with host draws.
+constexpr int RPB = 1024;
+__global__ void __launch_bounds__(RPB) replay_pop_kernel(const uint8_t* __restrict__ ep_info, int B, const int32_t* __restrict__ q_rows,
+                                                         const int32_t* __restrict__ q_seeds, int K, int32_t* __restrict__ cursor,
+                                                         int32_t* __restrict__ overflow, int32_t* __restrict__ level_idx,
+                                                         int32_t* __restrict__ cur_seed, uint8_t* __restrict__ solved) {
+  __shared__ int wave_count[RPB / WAVE];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) base = *cursor;
+  __syncthreads();
+  for (int e0 = 0; e0 < B; e0 += RPB) {
+    const int env = e0 + tid;
+    const bool fin = env < B && (ep_info[env] & DCD_INFO_EPISODE);
+    const unsigned long long bal = __ballot(fin);
+    if (lane == 0) wave_count[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < RPB / WAVE; ++w) { const int c = wave_count[w]; before += (w < wave) ? c : 0; total += c; }
+    const int slot = base + before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (env < B) {
+      int r = -1;
+      if (fin) {
+        if (slot < K) { r = q_rows[slot]; cur_seed[env] = q_seeds[slot]; if (solved) solved[env] = 1; }
+        else *overflow = 1;
+      }
+      level_idx[env] = r;
+    }
+    __syncthreads();
+    if (tid == 0) base += total;
+    __syncthreads();
+  }
+  if (tid == 0) *cursor = base;
 }
 
 __global__ void set_seed_kernel(uint8_t* rec, uint32_t* seed, const int64_t* seeds, int B) {
@@ -887,6 +945,31 @@ int dcd_mg_reset_to_actions(DcdMg* h, const int64_t* actions, const int32_t* len
   if (n < 0 || (!idx && n != h->p.B)) return dcd::fail("dcd_mg_reset_to_actions: n=%d must equal num_envs=%d when idx is NULL", n, h->p.B);
   LevelArgs a = base_args(h); a.loc = actions; a.lens = lens; a.max_len = max_len; a.idx = idx; a.n_rows = n; if (out) a.stu = *out;
   return launch_level<OP_REPLAY>(h, a, stream);
+}
+int dcd_mg_reset_to_encoding_rows(DcdMg* h, const uint8_t* table, const int32_t* level_idx, const DcdStudentObs* out, void* stream) {
+  CHECK_H(h);
+  NO_BIG(h, "dcd_mg_reset_to_encoding_rows");
+  if (!table || !level_idx) return dcd::fail("dcd_mg_reset_to_encoding_rows: null table / level_idx");
+  LevelArgs a = base_args(h); a.enc = table; a.level_idx = level_idx; a.idx = nullptr; a.n_rows = h->p.B; if (out) a.stu = *out;
+  return launch_level<OP_SET_ENCODING>(h, a, stream);
+}
+int dcd_mg_reset_to_actions_rows(DcdMg* h, const int64_t* table, const int32_t* table_lens, int32_t max_len, const int32_t* level_idx,
+                                 const DcdStudentObs* out, void* stream) {
+  CHECK_H(h);
+  NO_BIG(h, "dcd_mg_reset_to_actions_rows");
+  if (!table || !table_lens || !level_idx) return dcd::fail("dcd_mg_reset_to_actions_rows: null table / lens / level_idx");
+  LevelArgs a = base_args(h); a.loc = table; a.lens = table_lens; a.max_len = max_len; a.level_idx = level_idx; a.idx = nullptr; a.n_rows = h->p.B;
+  if (out) a.stu = *out;
+  return launch_level<OP_REPLAY>(h, a, stream);
+}
+int dcd_replay_pop(const uint8_t* ep_info, int32_t B, const int32_t* queue_rows, const int32_t* queue_seeds, int32_t K, int32_t* cursor,
+                   int32_t* overflow, int32_t* level_idx, int32_t* cur_seed, uint8_t* solved, void* stream) {
+  if (!ep_info || !queue_rows || !queue_seeds || !cursor || !overflow || !level_idx || !cur_seed || B <= 0 || K < 0)
+    return dcd::fail("dcd_replay_pop: NULL pointer or empty batch");
+  hipLaunchKernelGGL(replay_pop_kernel, dim3(1), dim3(RPB), 0, (hipStream_t)stream, ep_info, B, queue_rows, queue_seeds, K, cursor, overflow,
+                     level_idx, cur_seed, solved);
+  HIP_OK(hipGetLastError());
+  return 0;
 }
 int dcd_mg_mutate_level(DcdMg* h, int32_t num_edits, const DcdStudentObs* out, void* stream) {
   CHECK_H(h);

@@ -215,6 +215,18 @@ class MultiGridEngine:
             C.c_int32(max_len), ptr(idx, torch.int32, n, "idx"), C.c_int32(n), C.byref(st), stream_ptr()))
         return out
 
+    def reset_to_table_rows(self, table, table_lens, level_idx, out):
+        """Masked reset from a device level table (dcd_mg_reset_to_encoding_rows / _actions_rows): env i takes level
+        table[level_idx[i]] where level_idx[i] >= 0, everything else is left alone; `out` rows are indexed by env."""
+        st = self._student_struct(out, self.B)
+        if table.dtype == torch.uint8:
+            check(lib().dcd_mg_reset_to_encoding_rows(self._h, ptr(table, torch.uint8, name="table"), ptr(level_idx, torch.int32, self.B, "level_idx"),
+                                                      C.byref(st), stream_ptr()))
+        else:
+            check(lib().dcd_mg_reset_to_actions_rows(self._h, ptr(table, torch.int64, name="table"), ptr(table_lens, torch.int32, table.shape[0], "table_lens"),
+                                                     C.c_int32(table.shape[1]), ptr(level_idx, torch.int32, self.B, "level_idx"), C.byref(st), stream_ptr()))
+        return out
+
     def mutate_level(self, num_edits, out=None):
         out = self.student_buffers() if out is None else out
         st = self._student_struct(out, self.B)

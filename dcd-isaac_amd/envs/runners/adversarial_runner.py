@@ -73,7 +73,11 @@ class AdversarialRunner:
         # the RCCL path is exercised on a one-GPU box (tests/test_gpu_rccl_single.py)
         self.distributed = process_group is not None
         self.prefetch_draws = os.environ.get("DCD_PREFETCH_DRAWS", "1") != "0"
-        self.prefetch_stream_factor = int(os.environ.get("DCD_PREFETCH_STREAM", "3"))
+        # DCD_REPLAY_QUEUE=1 (default; one process only): a replay rollout takes the levels of its finished episodes from a
+        # device-resident queue of the sampler's speculated draws — ONE graph and one synchronisation per rollout instead of one
+        # per step (_queued_replay_rollout); the stream is then speculated 8 draws per env ahead instead of 3
+        self.replay_queue = os.environ.get("DCD_REPLAY_QUEUE", "1") != "0"
+        self.prefetch_stream_factor = int(os.environ.get("DCD_PREFETCH_STREAM", "8" if self.replay_queue else "3"))
         if process_group is not None:
             import torch.distributed as dist
             self.world_size = dist.get_world_size(process_group)
@@ -586,7 +590,10 @@ class AdversarialRunner:
             fused.begin_rollout(num_steps)
         body = lambda t0, t1: self._student_rollout_body(agent, num_steps, t0, t1, level_replay, level_sampler, rollout_info)
         can_graph = self.use_hip_graphs and (fused is not None or self.graph_pytorch_nets)
-        if host_resampling and can_graph:
+        if (host_resampling and can_graph and fused is not None and self.replay_queue and not self.distributed
+                and self._queued_replay_rollout(agent, num_steps, level_sampler, rollout_info)):
+            pass                                                        # the whole rollout ran as one graph on queued draws
+        elif host_resampling and can_graph:
             # Replay rollouts re-sample a level for every finished episode ON THE HOST between two steps (:551-558): the
             # device part of a step (policy, env step, bookkeeping) is one small HIP graph per step index, replayed, then
             # the host looks at the finished mask.  (Eager launches made this rollout 120 ms against 16 ms of GPU work.)
@@ -617,6 +624,71 @@ class AdversarialRunner:
         agent.storage.step = 0
         agent.storage.mark_obs_stale()
         self.venv.raise_errors()
+
+    # ---- replay rollouts on a device-resident queue of draws ---------------------------------------------------------------
+    # adversarial_runner.py:551-558 draws a replay level for every finished env, in env order, between two steps.  Those draws
+    # are one sequential stream of the sampler (level_sampler.py:664-680) that the host has already speculated ahead while the
+    # GPU ran the previous PPO update (LevelSampler.prefetch_next_update).  Its next entries — seed and level-table row — are
+    # uploaded once; at every step `dcd_replay_pop` hands them to the finished envs in env order and a masked level reset
+    # (dcd_mg_reset_to_*_rows) loads them, observations landing in the rollout buffers in place: the rollout is ONE graph
+    # with one synchronisation at its end.  The host then pops exactly the consumed prefix from the sampler
+    # (sample_replay_levels(consumed): same seeds, same np.random consumption, same staleness as 256 per-step requests — the
+    # stream does not depend on how requests cut it).  If the queue runs dry (more finished episodes than speculated draws) the
+    # kernel raises a flag: the env batch is restored from the snapshot taken before the rollout (the twin replica) and the
+    # rollout is redone on the per-step host path — same result, deterministically.
+    def _queued_replay_rollout(self, agent, num_steps, level_sampler, rollout_info):
+        import ctypes as C
+        B, st, venv, dev = self.args.num_processes, agent.storage, self.venv, self.device
+        if not hasattr(level_sampler, "peek_stream") or venv.engine.cfg.replicas < 2:
+            return False
+        kmax = self.prefetch_stream_factor * B
+        queue = level_sampler.peek_stream(min(B, kmax), kmax)
+        if not queue:
+            return False
+        q = getattr(self, "_replay_q", None)
+        if q is None or q["rows"].numel() != kmax:
+            i32 = dict(dtype=torch.int32, device=dev)
+            q = self._replay_q = dict(rows=torch.full((kmax,), -1, **i32), seeds=torch.zeros((kmax,), **i32), state=torch.zeros((2,), **i32),
+                                      level_idx=torch.full((B,), -1, **i32), solved=torch.zeros((B,), dtype=torch.uint8, device=dev))
+        rows = self._level_rows(queue)                                   # uploads what the table lacks (may reallocate it)
+        q["rows"].fill_(-1)
+        q["rows"][:len(queue)].copy_(rows.to(torch.int32))
+        q["seeds"][:len(queue)].copy_(torch.tensor(queue, dtype=torch.int32), non_blocking=True)
+        q["state"].zero_()                                               # [cursor, overflow]
+        q["solved"].zero_()
+        venv.clone_to_twin()                                             # snapshot: records, Philox keys / counters, metrics
+        seeds_before = self._seeds_dev.clone()
+        fused = self._fused_actor(agent)
+        L = dcd_hip.lib()
+        table, lens = self._table, getattr(self, "_table_len", None)
+
+        def body(t0, t1):
+            for t in range(t0, t1):
+                self._student_rollout_body(agent, num_steps, t, t + 1, False, level_sampler, rollout_info)
+                dcd_hip.check(L.dcd_replay_pop(dcd_hip.ptr(st.ep_info[t], torch.uint8, B, "ep_info"), C.c_int32(B), dcd_hip.ptr(q["rows"]),
+                                               dcd_hip.ptr(q["seeds"]), C.c_int32(kmax), C.c_void_p(q["state"].data_ptr()),
+                                               C.c_void_p(q["state"].data_ptr() + 4), dcd_hip.ptr(q["level_idx"]),
+                                               dcd_hip.ptr(self._seeds_dev, torch.int32, B, "seeds"), dcd_hip.ptr(q["solved"]), dcd_hip.stream_ptr()))
+                venv.engine.reset_to_table_rows(table, lens, q["level_idx"], st.student_obs_out(t + 1))
+        # the graph holds the level table's address: a reallocated table (grown by _store_rows) gets a new graph
+        key = ("student-queue", id(agent), num_steps, bool(agent.actor_critic.random), table.data_ptr(), 0 if lens is None else lens.data_ptr())
+        for k in [k for k in self._graphs if k[0] == "student-queue" and k[1] == id(agent) and k != key]:
+            del self._graphs[k]
+        self._graphed(key, num_steps, body)
+        consumed, overflow = q["state"].cpu().tolist()                   # the rollout's one synchronisation
+        if overflow:
+            venv.engine.clone_levels(venv.twin)                          # roll the env batch back; the host path redoes the rollout
+            self._seeds_dev.copy_(seeds_before)
+            self.replay_queue_overflows = getattr(self, "replay_queue_overflows", 0) + 1
+            return False
+        seeds = level_sampler.sample_replay_levels(consumed)
+        if list(seeds) != queue[:consumed]:
+            raise RuntimeError("replay queue: the sampler handed out other draws than the ones that were queued")
+        self.current_level_seeds[:] = self._seeds_dev.view(-1).cpu().tolist()
+        solved = q["solved"].cpu().numpy().astype(bool)
+        rollout_info["solved_idx"][solved] = True
+        self.replay_queue_rollouts = getattr(self, "replay_queue_rollouts", 0) + 1
+        return True
 
     def _fused_actor(self, agent):
         """dcd_hip.policy.StudentActor for this agent's network (act + insert_policy as two HIP kernels and one

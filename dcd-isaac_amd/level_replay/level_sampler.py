@@ -523,6 +523,22 @@ class LevelSampler:
         job["used"] = lo + n
         return seeds
 
+    def peek_stream(self, min_k, max_k):
+        """The next draws of the OPEN stream (the ones `sample_replay_levels` would hand out next) without consuming them:
+        waits until at least `min_k` are speculated, returns up to `max_k` of what is there — or None when no stream is open
+        or it ends before `min_k`.  The device-side replay queue (adversarial_runner.py: _queued_replay_rollout) uploads them,
+        lets the rollout consume a prefix on the GPU and then pops exactly that prefix with sample_replay_levels(consumed)."""
+        job = self.__dict__.get("_prefetch")
+        if job is None or job["stage"] != 2:
+            return None
+        with job["cv"]:
+            while job["produced"] < job["used"] + min_k and not job["finished"]:
+                job["cv"].wait()
+            have = job["produced"] - job["used"]
+            if have < min_k:
+                return None
+            return list(job["q_seeds"][job["used"]:job["used"] + min(have, max_k)])
+
     def _settle_if_streaming(self):
         """State-changing entry points end an OPEN stream first (its staleness is installed on settling); a speculation
         that has not been consumed yet (stage 0 / 1) is left to its own validity check."""

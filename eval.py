@@ -140,7 +140,8 @@ if __name__ == "__main__":
     venv, _ = create_parallel_env(targs, device="cuda:0")
     agent = make_agent("agent", venv, targs, "cuda:0")
     if a.model_tar:
-        sd = torch.load(a.model_tar, map_location="cuda:0", weights_only=False)
+        from util import load_checkpoint_safe                      # allow-list unpickler: nothing the file names is executed
+        sd = load_checkpoint_safe(a.model_tar, map_location="cuda:0")
         agent.algo.actor_critic.load_state_dict(sd["runner_state_dict"]["agent_state_dict"]["agent"])
     ev = Evaluator(a.env_names.split(","), a.num_processes, a.num_episodes, device="cuda:0")
     print(json.dumps(ev.evaluate(agent, deterministic=a.deterministic)))

@@ -191,6 +191,24 @@ int dcd_mg_reset_to_fixed_level(DcdMg* h, const uint8_t* enc, const int32_t* idx
 int dcd_mg_reset_to_actions(DcdMg* h, const int64_t* actions, const int32_t* lens,
                             int32_t max_len, const int32_t* idx, int32_t n,
                             const DcdStudentObs* out, void* stream);
+/* The two resets above for a MASKED subset of the batch, levels taken from a device-resident TABLE (the runner's mirror of the
+ * level store): level_idx int32[B]; env i is reset to level table[level_idx[i]] when level_idx[i] >= 0 and left untouched —
+ * record, metrics, outputs — otherwise.  `out` rows are indexed by env (the caller passes the rollout buffers' next-step rows:
+ * observations of re-sampled envs land in place).  Fixed launch shape whatever the number of resets: what a captured replay
+ * rollout needs (adversarial_runner.py:551-558 with the host decisions replaced by dcd_replay_pop's).
+ * table: uint8[rows,S,S,3] encodings, or int64[rows,max_len] teacher actions with table_lens int32[rows]. */
+int dcd_mg_reset_to_encoding_rows(DcdMg* h, const uint8_t* table, const int32_t* level_idx, const DcdStudentObs* out, void* stream);
+int dcd_mg_reset_to_actions_rows(DcdMg* h, const int64_t* table, const int32_t* table_lens, int32_t max_len, const int32_t* level_idx,
+                                 const DcdStudentObs* out, void* stream);
+/* Per-episode re-sampling of a replay rollout without the host (adversarial_runner.py:551-558; level_sampler.py:664-680).
+ * The reference draws one replay level per finished env, in env order, between two steps; the draws are one sequential stream
+ * of the sampler, speculated ahead by the host (LevelSampler.prefetch_next_update): queue_rows / queue_seeds int32[K] hold its
+ * next K entries (table row and level seed).  In env order, the k-th env with DCD_INFO_EPISODE set in ep_info uint8[B] takes
+ * entry *cursor + k: level_idx[env] = its table row, cur_seed[env] = its seed, solved[env] = 1 (optional); other envs get
+ * level_idx -1.  *cursor advances by the number of finished envs; entries past K set *overflow (those envs get -1): the caller
+ * must then discard the rollout and redo it with host draws. */
+int dcd_replay_pop(const uint8_t* ep_info, int32_t B, const int32_t* queue_rows, const int32_t* queue_seeds, int32_t K, int32_t* cursor,
+                   int32_t* overflow, int32_t* level_idx, int32_t* cur_seed, uint8_t* solved, void* stream);
 /* AdversarialEnv.mutate_level (adversarial.py:317-397), whole batch. */
 int dcd_mg_mutate_level(DcdMg* h, int32_t num_edits, const DcdStudentObs* out, void* stream);
 

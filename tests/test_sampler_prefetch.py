@@ -137,3 +137,52 @@ def test_streamed_per_step_draws_equal_the_sequential_order(chunk, extra, monkey
     for x, y in zip(a, b):
         assert x[0] == y[0] and x[1] == y[1] and x[2] == y[2], "decisions / seeds"
         assert np.array_equal(x[3], y[3]) and _same(x[4], y[4])
+
+
+@pytest.mark.parametrize("chunk,extra", [(512, 300), (16, 300), (16, 40)])
+def test_peeked_then_popped_prefix_equals_per_step_requests(chunk, extra, monkeypatch):
+    """The device replay queue's use of the stream (adversarial_runner._queued_replay_rollout): peek the next draws without
+    consuming, let the rollout take a prefix, then pop exactly that prefix in ONE request — seeds, staleness, weights and the
+    position of np.random equal the run that asks a few per step.  peek beyond the speculation returns what is there (or None)."""
+    from level_replay import LevelSampler
+    monkeypatch.setattr(LevelSampler, "STREAM_CHUNK", chunk)
+    B = 32
+    runs = []
+    for bulk in (False, True):
+        np.random.seed(33)
+        s = _sampler(B, N=80)
+        req = np.random.default_rng(8)
+        log = []
+        for it in range(6):
+            s.prefetch_next_update(B, stream_extra=extra)
+            d = s.sample_replay_decision()
+            seeds = s.sample_replay_levels(B) if d else None
+            got = []
+            if d:
+                counts = [int(req.integers(0, 5)) for _ in range(30)]
+                total = min(sum(counts), extra)
+                if bulk:
+                    peek = s.peek_stream(extra, extra)                     # (waits for the whole speculation: deterministic test)
+                    assert peek is not None and len(peek) == extra
+                    assert len(s.peek_stream(1, 5)) == 5
+                    before = _state(s)
+                    assert s.peek_stream(extra + 1, extra + 1) is None      # more than was speculated: not served
+                    assert _same(before, _state(s))                       # peeking moved nothing
+                    total = min(total, len(peek))
+                    got = s.sample_replay_levels(total)
+                    assert got == peek[:total]
+                else:
+                    left = total
+                    for c in counts:
+                        c = min(c, left)
+                        got += s.sample_replay_levels(c)
+                        left -= c
+            w = s.sample_weights().copy()
+            log.append((d, seeds, got, w, _state(s)))
+            s.seed_scores[(7 * it) % 80] = np.random.rand()
+            s.after_update()
+        runs.append(log)
+    assert sum(1 for x in runs[0] if x[0]) >= 2
+    for x, y in zip(*runs):
+        assert x[0] == y[0] and x[1] == y[1] and x[2] == y[2]
+        assert np.array_equal(x[3], y[3]) and _same(x[4], y[4])
