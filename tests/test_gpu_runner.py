@@ -362,8 +362,11 @@ def test_paired_lockstep_training_runs_with_graphs_and_plr(monkeypatch):
 def test_replay_rollouts_from_per_step_graphs_equal_eager_rollouts(monkeypatch):
     """Robust PLR: a replay rollout re-samples a level for every finished episode on the host between two steps; its
     device part runs from one small HIP graph per step index (third replay rollout on).  Same seeds, DCD_HIP_GRAPHS=1 vs
-    0: identical replay decisions, level seeds, sampler state and student storage after 14 updates."""
+    0: identical replay decisions, level seeds, sampler state and student storage after 14 updates.  (DCD_REPLAY_QUEUE=0: since
+    round 4 the default takes finished episodes' levels from a device queue instead — tests/test_gpu_replay_queue.py — and this
+    per-step path is what it falls back to.)"""
     res = {}
+    monkeypatch.setenv("DCD_REPLAY_QUEUE", "0")
     for mode in ("1", "0"):
         monkeypatch.setenv("DCD_HIP_GRAPHS", mode)
         args = make_args(ued_algo="domain_randomization", use_plr=True, use_reset_random_dr=True, no_exploratory_grad_updates=True,
