@@ -97,3 +97,22 @@ def test_train_cli_two_ranks_robust_plr(tmp_path):
     assert len(rows) == 6                                            # 24576 / (2 ranks x 32 envs x 64 steps)
     assert int(float(rows[-1]["steps"])) == 6 * 2 * 32 * 64          # job-wide step count (summed over ranks)
     assert all(r["agent_plr_passable_mass"] != "" for r in rows)
+
+
+def test_wall_limit_checkpoints_leaves_and_a_second_run_resumes(tmp_path):
+    """--wall_limit_s (this engine's addition; what tools/dr_pin.sh slices a 250 M-step run with): the loop checkpoints and
+    leaves once the budget is spent; the same command line run again continues from that update and finishes the job."""
+    common = [sys.executable, "train.py", "--xpid=wall", f"--log_dir={tmp_path}", "--env_name=MultiGrid-MiniGoalLastAdversarial-v0",
+              "--ued_algo=domain_randomization", "--use_plr=True", "--level_replay_prob=0.0", "--num_processes=32", "--num_steps=32",
+              "--ppo_epoch=1", "--handle_timelimits=True", "--log_interval=1", "--test_interval=0", "--checkpoint=True",
+              "--checkpoint_interval=1000", "--num_env_steps=40960"]                       # 40 updates
+    out = _run(common + ["--wall_limit_s=0.000001"])                  # spent before the first update: checkpoint of update 0, nothing logged
+    assert '"wall_limit_reached_at_update": 0' in out
+    d = os.path.join(str(tmp_path), "wall")
+    assert os.path.exists(os.path.join(d, "model.tar"))
+    out = _run(common + ["--wall_limit_s=3600"])
+    assert "wall_limit_reached" not in out
+    rows = _rows(os.path.join(d, "logs.csv"))
+    assert len(rows) == 40 and int(float(rows[-1]["steps"])) == 40960
+    sd = torch.load(os.path.join(d, "model.tar"), map_location="cpu", weights_only=False)["runner_state_dict"]
+    assert sd["num_updates"] == 40
