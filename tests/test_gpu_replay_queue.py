@@ -121,7 +121,7 @@ def test_queued_replay_rollouts_equal_the_host_path(monkeypatch, kw):
     """Byte-encoded levels (use_reset_random_dr) and teacher-action levels (the random teacher's strings)."""
     host = _run(monkeypatch, "0", "3", **kw)
     dev = _run(monkeypatch, "1", "8", **kw)
-    assert host["queued"] == 0 and dev["queued"] >= 2 and dev["overflows"] == 0
+    assert host["queued"] == 0 and dev["queued"] >= 3 and dev["overflows"] == 0     # >= 3: eager, captured, replayed from the graph
     assert sum(x[0] for x in host["log"]) >= 2
     _same(host, dev)
 
