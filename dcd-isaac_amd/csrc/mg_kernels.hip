@@ -119,60 +119,6 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
   uint8_t* __restrict__ u8 = o.image_u8 ? o.image_u8 + out_row0 * (3 * VV) : nullptr;
   if (f32 || u8) {
     int code[ITERS];
-    if constexpr (ITERS > 1) {
-      // Wide workgroups (several slots per thread): the straight loop below compiles to one slot after the other, each with two
-      // DEPENDENT LDS round trips behind exec-mask branches (dynamic state, then the cell), i.e. 2 x ITERS exposed LDS latencies
-      // per thread.  Here the slots go in groups of G: every dynamic-state word of a group is requested first, then every cell,
-      // branch-free (dead slots read row 0 and are dropped at the store) — two round trips per group, and few enough live
-      // registers to keep 8 waves per SIMD (all ITERS slots at once needed 112 VGPRs: occupancy 4).
-      constexpr int G = 4;
-#pragma unroll
-      for (int g0 = 0; g0 < ITERS; g0 += G) {
-        uint32_t dynw[G];
-        int addr[G];                                            // LDS address | own << 30 | out of bounds << 31
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-          const int i = g0 + j;
-          if (i < ITERS) {
-            const int q = i * NT + tid, row = q / TPE, ci = q & (TPE - 1);
-            const bool live = row < n && ci < VV && (!valid || valid[row] >= 0);
-            addr[j] = (live ? row : 0) * LP;
-            code[i] = live ? 0 : -1;
-            dynw[j] = *reinterpret_cast<const uint32_t*>(lds + addr[j] + DYN);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-          const int i = g0 + j;
-          if (i < ITERS) {
-            const int ci = (i * NT + tid) & (TPE - 1), vx = ci / V, vy = ci - vx * V;
-            const uint32_t dyn = dynw[j];
-            const int ax = dyn & 255, ay = (dyn >> 8) & 255, d = (dyn >> 16) & 255;
-            const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
-            const int wx = ax + fx * (V - 1 - vy) - fy * (vx - H), wy = ay + fy * (V - 1 - vy) + fx * (vx - H);
-            const bool own = (vx == H && vy == V - 1), oob = (wx < 0 || wx >= S || wy < 0 || wy >= S);
-            addr[j] = (addr[j] + ((own || oob) ? DYN + 3 : wy * ROW + wx)) | (own ? (1 << 30) : 0) | (oob ? (1 << 31) : 0);
-          }
-        }
-        int cell[G];
-#pragma unroll
-        for (int j = 0; j < G; ++j) if (g0 + j < ITERS) cell[j] = lds[addr[j] & 0xFFFFFF];
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-          const int i = g0 + j;
-          if (i < ITERS) {
-            const uint32_t dyn = dynw[j];
-            const int d = (dyn >> 16) & 255;
-            const bool own = (addr[j] >> 30) & 1, oob = (addr[j] >> 31) & 1;
-            int c = cell[j];
-            if (oob && !own) c = C_WALL_GREY;
-            else if (!own && c >= C_AGENT0 && c < C_DOOR0) c = C_AGENT0 + (((c - C_AGENT0) - (d + 1)) & 3);
-            c = ((dyn & 255) == NOPOS) ? 64 : c;
-            code[i] = code[i] < 0 ? -1 : c;
-          }
-        }
-      }
-    } else
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {                         // phase 1: all LDS gathers in flight together
       const int q = i * NT + tid, row = q / TPE, ci = q & (TPE - 1), vx = ci / V, vy = ci - vx * V;
@@ -201,25 +147,6 @@ __device__ __forceinline__ void render_emit(const uint8_t* lds, const Luts& lut,
       }
     }
     __builtin_amdgcn_sched_barrier(0);                       // keep the gathers batched ahead of the LUT/store phase
-    if (ITERS > 1 && u8 && !f32) {                           // wide workgroups, raw-u8 emission: the LUT reads of a group of slots
-      constexpr int G = 4;                                     // in flight together, then the group's stores (see phase 1)
-#pragma unroll
-      for (int g0 = 0; g0 < ITERS; g0 += G) {
-        uint32_t t[G];
-#pragma unroll
-        for (int j = 0; j < G; ++j) if (g0 + j < ITERS) t[j] = lut.enc[(code[g0 + j] < 0 || code[g0 + j] == 64) ? 0 : code[g0 + j]];
-#pragma unroll
-        for (int j = 0; j < G; ++j) {
-          const int i = g0 + j;
-          if (i < ITERS && code[i] >= 0) {
-            const int q = i * NT + tid, row = q / TPE, ci = q & (TPE - 1);
-            const uint32_t tv = code[i] == 64 ? 0u : t[j];
-            const unsigned uo = (unsigned)(row * (3 * VV) + ci * 3);
-            st_out<NTS>(&u8[uo], (uint8_t)tv); st_out<NTS>(&u8[uo + 1], (uint8_t)(tv >> 8)); st_out<NTS>(&u8[uo + 2], (uint8_t)(tv >> 16));
-          }
-        }
-      }
-    } else
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {                         // phase 2: LUT + stores
       const int q = i * NT + tid, row = q / TPE, ci = q & (TPE - 1);
@@ -324,7 +251,7 @@ struct StepRes { float reward, ep_ret; int ep_len; uint32_t flags; uint32_t doff
 // scalar outputs and the record write-back before they join the render — and no staging buffer for terminal observations: the
 // logic wave writes the (rare) pre-reset view straight to global memory.
 template <bool RANDOM, int EPB, bool RR, bool PAIR = false, bool OBS8 = false, bool LEAN = false>
-__global__ void __launch_bounds__(Threads<EPB>::value + (LEAN ? 0 : 2 * WAVE), LEAN ? 8 : 1) mg_step_kernel(const uint8_t* __restrict__ rec_in,
+__global__ void __launch_bounds__(Threads<EPB>::value + (LEAN ? 0 : 2 * WAVE)) mg_step_kernel(const uint8_t* __restrict__ rec_in,
                                                                                  const uint32_t* __restrict__ seed_in,
                                                                                  const int64_t* __restrict__ actions_in, int B_in,
                                                                                  const int64_t* __restrict__ actions1_in,

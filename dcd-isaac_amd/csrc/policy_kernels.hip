@@ -313,28 +313,29 @@ __global__ void __launch_bounds__(CB) policy_cell_heads_kernel(CellSets S) {
 // models/common.py:157-207: the flattened (T*N) sequence is cut wherever ANY env has mask 0 and the state is
 // re-masked at each cut == multiplying (h, c) by masks[t] before EVERY step.  Per step the recurrence is one
 // GEMM (gates = xp[t] + hm @ W_hh^T, rocBLAS) and ONE pointwise kernel here; backward likewise.  Everything
-// the backward needs is written by the forward into [T,N,*] buffers (activated gates, cell state, masked h).
+// the backward needs sits in [T,N,*] buffers after the forward (pre-activation gates — the GEMMs' outputs —, cell state, masked h).
 constexpr int LB = 256;
 
-// gates: [N,4H] pre-activation in, ACTIVATED (i,f,g,o) out (saved for backward).  c_prev: C[t-1] (or c0),
+// gates: [N,4H] pre-activations (i,f,g,o), left as they are — the backward kernel recomputes the four activations from them
+// (round 4: writing the activated gates back was a third of this kernel's 50 MB per step; the recomputation is 4 transcendentals
+// per element on values the backward reads anyway, bit-identical to what was stored).  c_prev: C[t-1] (or c0),
 // m_t: masks[t] (applied to c_prev here; h was masked when hm[t] was formed).  m_next: masks[t+1] or NULL.
-__global__ void __launch_bounds__(LB) lstm_seq_fwd_kernel(float* __restrict__ gates, const float* __restrict__ c_prev,
+__global__ void __launch_bounds__(LB) lstm_seq_fwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
                                                           const float* __restrict__ m_t, const float* __restrict__ m_next,
                                                           float* __restrict__ c_out, float* __restrict__ h_out,
                                                           float* __restrict__ hm_next, int N, int H) {
   const int q = blockIdx.x * LB + threadIdx.x;
   if (q >= N * H) return;
   const int b = q / H, j = q - b * H;
-  float* g = gates + (size_t)b * 4 * H;
+  const float* g = gates + (size_t)b * 4 * H;
   const float i = sigmoidf_(g[j]), f = sigmoidf_(g[H + j]), gg = tanhf(g[2 * H + j]), o = sigmoidf_(g[3 * H + j]);
   const float c = f * (c_prev[q] * m_t[b]) + i * gg;
   const float h = o * tanhf(c);
-  g[j] = i; g[H + j] = f; g[2 * H + j] = gg; g[3 * H + j] = o;
   c_out[q] = c; h_out[q] = h;
   if (hm_next) hm_next[q] = h * m_next[b];
 }
 
-// step t of the backward.  act: activated gates of step t; c_t, c_prev (C[t-1] or c0); m_t = masks[t];
+// step t of the backward.  act: PRE-activation gates of step t (activated here, as the forward did); c_t, c_prev (C[t-1] or c0); m_t = masks[t];
 // dout: grad wrt h_t from the heads; dhm_next: DG[t+1] @ W_hh (raw; NULL at t = T-1), m_next = masks[t+1];
 // dcf_next: dc_{t+1} * f_{t+1} (raw; NULL at T-1).  Writes dgates (pre-activation grads) and dcf = dc_t * f_t.
 __global__ void __launch_bounds__(LB) lstm_seq_bwd_kernel(const float* __restrict__ act, const float* __restrict__ c_t,
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(LB) lstm_seq_bwd_kernel(const float* __restric
   if (q >= N * H) return;
   const int b = q / H, j = q - b * H;
   const float* a = act + (size_t)b * 4 * H;
-  const float i = a[j], f = a[H + j], g = a[2 * H + j], o = a[3 * H + j];
+  const float i = sigmoidf_(a[j]), f = sigmoidf_(a[H + j]), g = tanhf(a[2 * H + j]), o = sigmoidf_(a[3 * H + j]);
   const float mn = m_next ? m_next[b] : 0.f;
   float dh = dout ? dout[q] : 0.f, dc = 0.f;
   if (dhm_next) dh += dhm_next[q] * mn;
@@ -943,7 +944,7 @@ int dcd_policy_cell_heads_pair(const DcdPolicyAgent* a0, const DcdPolicyAgent* a
   return cell_heads_sets(a0, a1, B, stream, "dcd_policy_cell_heads_pair");
 }
 
-int dcd_lstm_seq_fwd_step(float* gates, const float* c_prev, const float* m_t, const float* m_next, float* c_out, float* h_out,
+int dcd_lstm_seq_fwd_step(const float* gates, const float* c_prev, const float* m_t, const float* m_next, float* c_out, float* h_out,
                           float* hm_next, int32_t N, int32_t H, void* stream) {
   if (!gates || !c_prev || !m_t || !c_out || !h_out || N <= 0 || H <= 0) return dcd::fail("dcd_lstm_seq_fwd_step: NULL pointer or empty");
   if (hm_next && !m_next) return dcd::fail("dcd_lstm_seq_fwd_step: hm_next needs m_next");

@@ -520,12 +520,12 @@ int dcd_policy_cell_heads_pair(const DcdPolicyAgent* a0, const DcdPolicyAgent* a
  * cut — the same function as multiplying (h, c) by masks[t] before every step.  One step of that recurrence
  * is a GEMM (caller: gates = xp[t] + hm[t] @ W_hh^T) plus this pointwise kernel; the backward step likewise
  * (caller: dhm = dgates @ W_hh).  Gate order i,f,g,o (nn.LSTM).
- * fwd: gates float[N,4H] pre-activation in / ACTIVATED out (kept for the backward); c_prev float[N,H] = C[t-1]
+ * fwd: gates float[N,4H] pre-activations (read only; the backward step recomputes the activations from them); c_prev float[N,H] = C[t-1]
  * (unmasked; multiplied by m_t float[N] here); c_out, h_out float[N,H]; hm_next float[N,H] = h_out * m_next
  * (the next step's GEMM operand; NULL with m_next at the last step). */
-int dcd_lstm_seq_fwd_step(float* gates, const float* c_prev, const float* m_t, const float* m_next, float* c_out,
+int dcd_lstm_seq_fwd_step(const float* gates, const float* c_prev, const float* m_t, const float* m_next, float* c_out,
                           float* h_out, float* hm_next, int32_t N, int32_t H, void* stream);
-/* bwd of step t: act = activated gates, c_t, c_prev (unmasked C[t-1]), m_t; dout = dL/dh_t from the heads (or
+/* bwd of step t: act = the same PRE-activation gates the forward step read, c_t, c_prev (unmasked C[t-1]), m_t; dout = dL/dh_t from the heads (or
  * NULL); dhm_next = dgates[t+1] @ W_hh and dcf_next = dcf[t+1], both multiplied by m_next = masks[t+1] here
  * (all three NULL at t = T-1); dh_last / dc_last: grads of the returned final state (NULL if unused).
  * Writes dgates float[N,4H] (pre-activation grads: d xp[t]) and dcf float[N,H] = dL/dc_t * f_t. */
