@@ -132,7 +132,8 @@ class MultigridNetwork(DeviceAwareModule):
         else:
             xp[:N] = self.image_conv(img[0]) @ wf.t()                                        # t = 0: dense
         if M:
-            act = lambda rows: torch.relu(torch.addmm(conv.bias, flat[rows.unsqueeze(1), col], wc.t()))
+            # (`linear`: on >= 65 536 rows the weight gradient is a split-K contraction, models/common.py::matmul_tn)
+            act = lambda rows: torch.relu(linear(flat[rows.unsqueeze(1), col], wc, conv.bias))
             delta = act(row_t) - act(row_prev)                                               # [M, F] feature change per triple
         if M and batched:
             # One batched GEMM over the positions instead of P small ones (545 launches per epoch, host-bound and at

@@ -113,3 +113,21 @@ def test_unused_outputs_and_repeated_backward_of_one_update(monkeypatch):
             got[fused] = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in net.named_parameters()}
         for k in got[False]:
             _close(got[True][k], got[False][k], f"{use} grad {k}")
+
+
+@pytest.mark.parametrize("R", [65536, 131072 + 77, 1265777])
+def test_split_k_weight_gradient_with_a_row_count_no_power_of_two_divides(R):
+    """matmul_tn(a, b) = a^T b for tall operands: 256-way split of the largest multiple of 256 rows + the product of the rows
+    left over (the teacher's conv-window rows come in odd counts: 1 265 777 in a 4096 x 27 batch)."""
+    from models import common
+    g = torch.Generator().manual_seed(R % 1000)
+    a = torch.randn(R, 128, generator=g).to(DEV)
+    b = torch.randn(R, 27, generator=g).to(DEV)
+    ref = (a.double().t() @ b.double())
+    out = common.matmul_tn(a, b)
+    assert out.shape == (128, 27)
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) <= 2e-5 * scale
+    # ... and it is at least as close to the float64 product as the plain fp32 GEMM
+    plain = a.t() @ b
+    assert float((out.double() - ref).abs().max()) <= 2 * float((plain.double() - ref).abs().max()) + 1e-6 * scale
