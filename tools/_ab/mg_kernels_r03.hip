@@ -75,21 +75,6 @@ __device__ __forceinline__ void stage_load(StageBuf<ROWS, NT>& sb, const uint8_t
     if (row < n) sb.v[i] = *reinterpret_cast<const uint4*>(rec + (size_t)env_of(row) * REC_BYTES + c * 16);
   }
 }
-// The same for the MASKED level ops (round 4): env_of(row) < 0 marks a row the call leaves alone.  Separate functions: the
-// step kernel and the unmasked level ops keep the code they had (the B = 4096 launches are sensitive to where their hot code
-// falls: an innocent refactoring of this file cost the step kernel 10 % per launch, profiles/r04_ab_step_codegen.log).
-template <int ROWS, int NT, class RowToEnv>
-__device__ __forceinline__ void stage_load_masked(StageBuf<ROWS, NT>& sb, const uint8_t* __restrict__ rec, RowToEnv env_of, int n, int tid) {
-#pragma unroll
-  for (int i = 0; i < (ROWS * 16 + NT - 1) / NT; ++i) {
-    const int q = i * NT + tid, row = q >> 4, c = q & 15;
-    sb.v[i] = make_uint4(0, 0, 0, 0);
-    if (row < n) {
-      const int ev = env_of(row);
-      if (ev >= 0) sb.v[i] = *reinterpret_cast<const uint4*>(rec + (size_t)ev * REC_BYTES + c * 16);
-    }
-  }
-}
 template <int ROWS, int NT>
 __device__ __forceinline__ void stage_commit(const StageBuf<ROWS, NT>& sb, uint8_t* lds, int n, int tid) {
 #pragma unroll
@@ -103,14 +88,6 @@ __device__ __forceinline__ void stage_out(const uint8_t* lds, uint8_t* __restric
   for (int q = tid; q < n * 16; q += NT) {
     const int row = q >> 4, c = q & 15;
     *reinterpret_cast<uint4*>(rec + (size_t)env_of(row) * REC_BYTES + c * 16) = *reinterpret_cast<const uint4*>(lds + row * LP + c * 16);
-  }
-}
-template <int NT, class RowToEnv>
-__device__ __forceinline__ void stage_out_masked(const uint8_t* lds, uint8_t* __restrict__ rec, RowToEnv env_of, int n, int tid) {
-  for (int q = tid; q < n * 16; q += NT) {
-    const int row = q >> 4, c = q & 15;
-    const int ev = env_of(row);
-    if (ev >= 0) *reinterpret_cast<uint4*>(rec + (size_t)ev * REC_BYTES + c * 16) = *reinterpret_cast<const uint4*>(lds + row * LP + c * 16);
   }
 }
 
@@ -195,79 +172,6 @@ __device__ __forceinline__ void render_emit_v(const uint8_t* lds, const Luts& lu
   if (p.V == 5) render_emit<5, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls);
   else if (p.V == 7) render_emit<7, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls);
   else render_emit<3, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls);
-}
-
-// render_emit for the masked level ops (round 4): rows with valid[row] < 0 were left alone by the call and emit nothing.
-template <int V, int ROWS, int NT>
-__device__ __forceinline__ void render_emit_masked(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
-                                            int n, int S, int tid, int see_through, const int* valid) {
-  // TPE threads per env (power of two >= V*V): env = slot >> log2(TPE), view cell = slot & (TPE-1) — shifts
-  // and masks instead of divisions; all offsets are 32-bit from per-workgroup base pointers.
-  constexpr int VV = V * V, H = V / 2, TPE = VV <= 16 ? 16 : (VV <= 32 ? 32 : 64), ITERS = (ROWS * TPE + NT - 1) / NT;
-  constexpr bool NTS = ROWS == 64;
-  float* __restrict__ f32 = o.image_f32 ? o.image_f32 + out_row0 * (3 * VV) : nullptr;
-  uint8_t* __restrict__ u8 = o.image_u8 ? o.image_u8 + out_row0 * (3 * VV) : nullptr;
-  if (f32 || u8) {
-    int code[ITERS];
-#pragma unroll
-    for (int i = 0; i < ITERS; ++i) {                         // phase 1: all LDS gathers in flight together
-      const int q = i * NT + tid, row = q / TPE, ci = q & (TPE - 1), vx = ci / V, vy = ci - vx * V;
-      code[i] = -1;
-      if (row < n && ci < VV && (!valid || valid[row] >= 0)) {   // valid: rows of a masked level op that were left alone
-        const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + row * LP + DYN);
-        const int ax = dyn & 255, ay = (dyn >> 8) & 255, d = (dyn >> 16) & 255;
-        const int fx = (d == 0) - (d == 2), fy = (d == 1) - (d == 3);
-        const int wx = ax + fx * (V - 1 - vy) - fy * (vx - H), wy = ay + fy * (V - 1 - vy) + fx * (vx - H);
-        const bool own = (vx == H && vy == V - 1), oob = (wx < 0 || wx >= S || wy < 0 || wy >= S);
-        int c = lds[row * LP + ((own || oob) ? DYN + 3 : wy * ROW + wx)];        // own cell -> carrying byte
-        if (oob && !own) c = C_WALL_GREY;
-        else if (!own && c >= C_AGENT0 && c < C_DOOR0) c = C_AGENT0 + (((c - C_AGENT0) - (d + 1)) & 3);
-        code[i] = (ax == NOPOS) ? 64 : c;                      // 64: no agent placed yet -> zero observation
-      }
-    }
-    if (DCD_RARE(!see_through)) {
-#pragma unroll
-      for (int i = 0; i < ITERS; ++i) {
-        const int q = i * NT + tid, ci = q & (TPE - 1), vx = ci / V, vy = ci - vx * V;
-        const bool tr = code[i] >= 0 && code[i] != 64 && ((vx == H && vy == V - 1) || see_behind((uint8_t)code[i]));
-        const unsigned long long bal = __ballot(tr);
-        const unsigned long long mine = TPE == 64 ? bal : ((bal >> ((tid & 63) & ~(TPE - 1))) & ((1ull << (TPE & 63)) - 1ull));
-        const unsigned long long vis = process_vis_mask(mine, V);
-        if (code[i] >= 0 && !((vis >> ci) & 1)) code[i] = 64;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);                       // keep the gathers batched ahead of the LUT/store phase
-#pragma unroll
-    for (int i = 0; i < ITERS; ++i) {                         // phase 2: LUT + stores
-      const int q = i * NT + tid, row = q / TPE, ci = q & (TPE - 1);
-      if (code[i] < 0) continue;
-      const bool none = code[i] == 64;
-      const int c = none ? 0 : code[i];
-      const unsigned off = (unsigned)(row * (3 * VV) + ci);
-      if (f32) {
-        const float f0 = lut.f[0][c], f1 = lut.f[1][c], f2 = lut.f[2][c];
-        st_out<NTS>(&f32[off], none ? 0.f : f0); st_out<NTS>(&f32[off + VV], none ? 0.f : f1); st_out<NTS>(&f32[off + 2 * VV], none ? 0.f : f2);
-      }
-      if (u8) {
-        const uint32_t t = none ? 0u : lut.enc[c];
-        const unsigned uo = (unsigned)(row * (3 * VV) + ci * 3);
-        st_out<NTS>(&u8[uo], (uint8_t)t); st_out<NTS>(&u8[uo + 1], (uint8_t)(t >> 8)); st_out<NTS>(&u8[uo + 2], (uint8_t)(t >> 16));
-      }
-    }
-  }
-  if (tid < n && (!valid || valid[tid] >= 0)) {
-    const uint32_t dyn = *reinterpret_cast<const uint32_t*>(lds + tid * LP + DYN);
-    const int d = ((dyn & 255) == NOPOS) ? 0 : ((dyn >> 16) & 255);
-    if (o.dir_u8) st_out<(ROWS == 64)>(&o.dir_u8[out_row0 + tid], (uint8_t)d);
-    if (o.dir_f32) st_out<(ROWS == 64)>(&o.dir_f32[out_row0 + tid], (float)d);
-  }
-}
-template <int ROWS, int NT>
-__device__ __forceinline__ void render_emit_v_masked(const uint8_t* lds, const Luts& lut, const DcdStudentObs& o, size_t out_row0,
-                                              int n, const Params& p, int tid, const int* valid) {
-  if (p.V == 5) render_emit_masked<5, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls, valid);
-  else if (p.V == 7) render_emit_masked<7, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls, valid);
-  else render_emit_masked<3, ROWS, NT>(lds, lut, o, out_row0, n, p.S, tid, p.see_through_walls, valid);
 }
 
 // ---- emission of per-lane staged observations (terminal obs: rare) ---------------------------
@@ -483,179 +387,6 @@ __global__ void __launch_bounds__(Threads<EPB>::value + 2 * WAVE) mg_step_kernel
   }
 }
 
-// The LEAN wide step kernel (round 4; the bandwidth regime only: EPB = 64 with raw-u8 emission) — a copy of mg_step_kernel
-// above, specialised, as a function of its own so that the original keeps its code: 4 waves and 19 KB of LDS per workgroup instead of
-// 6 waves and 29.6 KB, i.e. 8 resident workgroups per CU instead of 5 (both limits, 32 wave slots and 160 KB, were at 5).  The SQ
-// counters of the 6-wave kernel at 1 M envs (profiles/r04_pmc_sq_wide_step_before.json) show waves PARKED 70 % of their cycles with
-// the vector ALUs 45 % busy: the launch is short of parallel slack, not of bandwidth.  No duty waves — waves 1 and 2 take the
-// scalar outputs and the record write-back before they join the render — and no staging buffer for terminal observations: the
-// logic wave writes the (rare) pre-reset view straight to global memory.
-template <bool RR, bool PAIR>
-__global__ void __launch_bounds__(Threads<64>::value) mg_step_lean_kernel(const uint8_t* __restrict__ rec_in,
-                                                                                 const uint32_t* __restrict__ seed_in,
-                                                                                 const int64_t* __restrict__ actions_in, int B_in,
-                                                                                 const int64_t* __restrict__ actions1_in,
-                                                                                 Params p, StepArgs a) {
-  constexpr bool RANDOM = false, OBS8 = true, LEAN = true;
-  constexpr int EPB = 64, NT = Threads<EPB>::value;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[EPB * LP];
-  __shared__ __attribute__((aligned(16))) uint8_t sterm[LEAN ? 16 : EPB * MAX_OP];
-  __shared__ StepRes res[EPB];
-  __shared__ uint8_t term_valid[EPB];
-  __shared__ int any_term;
-  __shared__ Luts lut;
-  const int tid = threadIdx.x;
-  int set = 0, blk = blockIdx.x;
-  if (PAIR) { const int bps = (B_in + EPB - 1) / EPB; if (blk >= bps) { set = 1; blk -= bps; } }
-  const int env0 = blk * EPB;                        // first env of this workgroup within its replica
-  const int row0 = PAIR ? set * B_in + env0 : env0;  // ... and its record row
-  const int n = min(EPB, B_in - env0), env = env0 + tid, row = row0 + tid;
-  const DcdStepOut& outs = a.out[PAIR ? set : 0];
-  STAMP(0);
-  // issue every independent global load up front: records, action, seed (one HBM round trip in all)
-  StageBuf<EPB, NT> sb;
-  if (tid < NT) stage_load<EPB, NT>(sb, rec_in, [row0](int r) { return row0 + r; }, n, tid);
-  int64_t act0 = 0; uint32_t seed = 0;
-  if (tid < n) { seed = seed_in[row]; if (!RANDOM) act0 = ((PAIR && set) ? actions1_in : actions_in)[env]; term_valid[tid] = 0; }
-  const int OP = obs_pitch(p.V);
-  if (tid == 0) any_term = 0;
-  init_luts<!OBS8>(lut, tid);
-  STAMP(1);
-  if (tid < NT) stage_commit<EPB, NT>(sb, lds, n, tid);
-  __syncthreads();
-  STAMP(2);
-
-  unsigned long long episodes = 0;
-  if (tid < WAVE) {                                  // the logic wave: lane <-> env for lanes < n, all 64 lanes for rare cooperative work
-    const bool live = tid < n;
-    const int step_flags = RR ? a.flags : (a.flags & ~DCD_STEP_RESET_RANDOM);
-    Env e = make_env(as_lds(lds + (live ? tid : 0) * LP), seed);
-    e.cache_side();
-    Metrics m = {0, 0, 0, 0}; bool mdirty = false;
-    if (RR && live && (step_flags & DCD_STEP_RESET_RANDOM)) m = a.met[row];
-    StepResult r = {};
-    const int K = RANDOM ? a.K : 1;
-    for (int k = 0; k < K; ++k) {
-      int64_t act = act0;
-      if (RANDOM) {
-        uint32_t o[4];
-        philox4x32_10(a.t0 + k, 0, 0, 0, a.action_seed, (uint32_t)(a.env_index_base + env), o);
-        act = (int64_t)mulhi32(o[0], 7u);
-      }
-      const int fl = (RANDOM && k != K - 1) ? (step_flags & ~DCD_STEP_LAST) : step_flags;
-      StepPre sp = {};
-      if (live) sp = env_step_pre(e, p, act);
-      // pre-reset observation of envs whose time limit fired (info['truncated_obs']): one view cell per lane
-      unsigned long long tm = __ballot(live && sp.have_term);
-      if (DCD_RARE(tm != 0)) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the owners' cell writes are visible to the wave
-        const int V = p.V, VV = V * V;
-        while (tm) {
-          const int src = __builtin_ctzll(tm); tm &= tm - 1;
-          const int ax = __shfl(e.ax, src), ay = __shfl(e.ay, src), ad = __shfl(e.adir, src), ca = __shfl(e.carrying, src);
-          auto rec = as_lds(lds + src * LP);
-          const int vx = tid / V, vy = tid - vx * V;
-          const uint8_t cc = tid < VV ? view_cell_code(rec, p.S, V, ax, ay, ad, ca, vx, vy) : C_WALL_GREY;
-          unsigned long long vis = ~0ull;
-          if (!p.see_through_walls)
-            vis = process_vis_mask(__ballot(tid < VV && ((vx == V / 2 && vy == V - 1) || see_behind(cc))), V);
-          const uint32_t t = (tid < VV && ((vis >> tid) & 1)) ? enc3(cc) : 0u;
-          if (LEAN) {                                                  // straight to info['truncated_obs'] (u8 emission only)
-            uint8_t* gi = outs.term_obs.image_u8;
-            if (gi && tid < VV) {
-              uint8_t* q = gi + (size_t)(env0 + src) * (VV * 3) + tid * 3;
-              q[0] = (uint8_t)t; q[1] = (uint8_t)(t >> 8); q[2] = (uint8_t)(t >> 16);
-            }
-            if (tid == 0 && outs.term_obs.dir_u8) outs.term_obs.dir_u8[env0 + src] = (uint8_t)ad;
-          } else {
-            auto out = as_lds(sterm + src * OP);
-            if (tid < VV) { out[tid * 3] = (uint8_t)t; out[tid * 3 + 1] = (uint8_t)(t >> 8); out[tid * 3 + 2] = (uint8_t)(t >> 16); }
-            if (tid == 0) out[VV * 3] = (uint8_t)ad;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      }
-      if (live) {
-        r = env_step_post(e, p, m, mdirty, fl, sp);
-        if (RANDOM) episodes += (r.info & DCD_INFO_EPISODE) ? 1 : 0;
-      }
-    }
-    if (live) {
-      if (!LEAN && DCD_RARE(r.have_term)) { term_valid[tid] = 1; any_term = 1; }
-      e.store_dyn();                                 // LDS copy feeds the render and the write-back wave
-      StepRes sr;
-      sr.reward = r.reward; sr.ep_ret = r.ep_ret; sr.ep_len = r.ep_len;
-      sr.flags = (uint32_t)r.done | ((uint32_t)r.info << 8) | ((uint32_t)(e.full_dirty ? 1 : 0) << 16) | ((uint32_t)(e.ctr_dirty ? 1 : 0) << 17) | ((uint32_t)min(e.nd, 2) << 20);
-      sr.doff = (uint32_t)e.doff0 | ((uint32_t)e.doff1 << 16);
-      res[tid] = sr;
-      if (RR && DCD_RARE(mdirty)) a.met[row] = m;
-      if (DCD_RARE(e.err)) raise(a.errs, e.err, env);
-    }
-    STAMP(3);
-  }
-  __syncthreads();
-  STAMP(4);
-  auto duty_scalars = [&](int l) {                    // per-env scalar outputs
-    const int ev = env0 + l;
-    if (l < n) {
-      const StepRes sr = res[l];
-      const uint32_t done = sr.flags & 255, info = (sr.flags >> 8) & 255;
-      const DcdStepOut& o = outs;
-      if (o.reward) st_out<(EPB == 64)>(&o.reward[ev], sr.reward);
-      if (o.done) st_out<(EPB == 64)>(&o.done[ev], (uint8_t)done);
-      if (o.info) st_out<(EPB == 64)>(&o.info[ev], (uint8_t)info);
-      if (o.ep_ret) st_out<(EPB == 64)>(&o.ep_ret[ev], sr.ep_ret);
-      if (o.ep_len) st_out<(EPB == 64)>(&o.ep_len[ev], (int32_t)sr.ep_len);
-      if (o.masks) st_out<(EPB == 64)>(&o.masks[ev], done ? 0.f : 1.f);                                // runner :566-573
-      if (o.bad_masks) st_out<(EPB == 64)>(&o.bad_masks[ev], (info & DCD_INFO_TRUNC_KEY) ? 0.f : 1.f);
-      if (o.cliffhanger_masks) st_out<(EPB == 64)>(&o.cliffhanger_masks[ev], (info & DCD_INFO_CLIFFHANGER) ? 0.f : 1.f);
-    }
-  };
-  auto duty_writeback = [&](int l) {                  // record write-back
-    if (l < n) {
-      const StepRes sr = res[l];
-      uint8_t* g = a.rec + (size_t)(row0 + l) * REC_BYTES;
-      const uint8_t* src = lds + l * LP;
-      if ((sr.flags >> 16) & 1) {
-        uint4 rows[16];
-#pragma unroll
-        for (int y = 0; y < 16; ++y) rows[y] = *reinterpret_cast<const uint4*>(src + y * ROW);
-#pragma unroll
-        for (int y = 0; y < 16; ++y) *reinterpret_cast<uint4*>(g + y * ROW) = rows[y];
-      } else {
-        const int nd = (sr.flags >> 20) & 3, o0 = sr.doff & 0xFFFF, o1 = sr.doff >> 16;
-        const uint4 dyn = *reinterpret_cast<const uint4*>(src + DYN);
-        const uint8_t c0 = src[o0], c1 = src[o1];
-        if (nd > 0) st_out<(EPB == 64)>(&g[o0], c0);
-        if (nd > 1) st_out<(EPB == 64)>(&g[o1], c1);
-        if ((sr.flags >> 17) & 1) {                      // the draw counter moved (a goal was reached): side bytes of rows 8..11
-#pragma unroll
-          for (int k = 8; k < 12; ++k) g[k * ROW + SIDE] = src[k * ROW + SIDE];
-        }
-        st_out<(EPB == 64)>(reinterpret_cast<u32x4*>(g + DYN), u32x4{dyn.x, dyn.y, dyn.z, dyn.w});
-      }
-    }
-  };
-  if (LEAN) {                                          // waves 1 and 2 issue the duty stores, then every wave renders
-    if (tid >= WAVE && tid < 2 * WAVE) duty_scalars(tid - WAVE);
-    else if (tid >= 2 * WAVE && tid < 3 * WAVE) duty_writeback(tid - 2 * WAVE);
-    render_emit_v<EPB, NT>(lds, lut, outs.obs, (size_t)env0, n, p, tid);
-  } else if (tid < NT) {
-    render_emit_v<EPB, NT>(lds, lut, outs.obs, (size_t)env0, n, p, tid);      // post-auto-reset observation
-    STAMP(5);
-    if (any_term) emit_staged<NT>(sterm, lut, outs.term_obs, (size_t)env0, n, p.V, tid, term_valid);
-    STAMP(6);
-  } else if (tid < NT + WAVE) {                      // duty wave A
-    duty_scalars(tid - NT);
-  } else {                                           // duty wave B
-    duty_writeback(tid - NT - WAVE);
-  }
-  if (RANDOM && a.n_episodes && tid < WAVE) {
-    for (int off = 32; off > 0; off >>= 1) episodes += __shfl_down(episodes, off);
-    if (tid == 0 && episodes) atomicAdd(a.n_episodes, episodes);
-  }
-}
-
 // =================================================================================== level ops
 enum LevelOp { OP_RESET = 0, OP_STEP_ADV, OP_RESET_AGENT, OP_RESET_RANDOM, OP_SET_ENCODING, OP_REPLAY, OP_MUTATE,
                OP_READ_ENC, OP_FIXED_LEVEL };
@@ -666,8 +397,6 @@ struct LevelArgs {
   const int64_t* loc;                             // OP_STEP_ADV [B]; OP_REPLAY actions [n,max_len]
   const int32_t* lens; int max_len;               // OP_REPLAY
   const uint8_t* enc;                             // OP_SET_ENCODING [n,S,S,3]
-  const int32_t* level_idx;                       // OP_SET_ENCODING / OP_REPLAY, optional [n_rows]: row r takes level level_idx[r] of enc /
-                                                  // loc / lens (a level TABLE) instead of level r; < 0: the row's env is left alone
   int num_edits;                                  // OP_MUTATE
   DcdAdvObs adv; uint8_t* adv_done;               // teacher outputs
   DcdStudentObs stu;                              // student outputs
@@ -712,30 +441,21 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
   __shared__ uint32_t bad_enc[DECODE ? EPB : 1];
   const int tid = threadIdx.x, row0 = blockIdx.x * EPB;
   const int n = min(EPB, n_rows_in - row0), row = row0 + tid;
-  constexpr bool CAN_MASK = (OP == OP_SET_ENCODING || OP == OP_REPLAY);
-  const int32_t* __restrict__ lvl = CAN_MASK ? a.level_idx : nullptr;
-  if (tid < EPB) {
-    int ev = (tid < n) ? (idx_in ? idx_in[row] : row) : -1;
-    if (CAN_MASK && lvl && ev >= 0 && lvl[row] < 0) ev = -1;
-    env_of[tid] = ev;
-  }
+  if (tid < EPB) env_of[tid] = (tid < n) ? (idx_in ? idx_in[row] : row) : -1;
   const int S = p.S;
   init_luts(lut, tid);
   if (DECODE && tid < EPB) bad_enc[tid] = 0;
   __syncthreads();
   {
     StageBuf<EPB, NT> sb;
-    if (CAN_MASK) stage_load_masked<EPB, NT>(sb, rec_in, [&](int r) { return env_of[r]; }, n, tid);
-    else stage_load<EPB, NT>(sb, rec_in, [&](int r) { return env_of[r]; }, n, tid);
+    stage_load<EPB, NT>(sb, rec_in, [&](int r) { return env_of[r]; }, n, tid);
     stage_commit<EPB, NT>(sb, lds, n, tid);
   }
   if (DECODE) {                                   // WorldObj.decode of every cell of every row (multigrid.py:264-280), one per thread
     const int SS = S * S;
     for (int q = tid; q < n * SS; q += NT) {
       const int r = q / SS, cell = q - r * SS;
-      const int src = (CAN_MASK && lvl) ? lvl[row0 + r] : row0 + r;
-      if (CAN_MASK && src < 0) continue;
-      const uint8_t* c = a.enc + ((size_t)src * SS + cell) * 3;
+      const uint8_t* c = a.enc + ((size_t)(row0 + r) * SS + cell) * 3;
       uint8_t code;
       if (!dec3(c[0], c[1], c[2], &code)) { atomicOr(&bad_enc[r], 1u); code = C_NONE; }
       codes[r * (MAX_SIZE * MAX_SIZE) + cell] = code;
@@ -744,7 +464,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
   __syncthreads();
 
   constexpr bool ADV_OUT = (OP == OP_RESET || OP == OP_STEP_ADV || OP == OP_READ_ENC);
-  if (tid < n && OP != OP_READ_ENC && (!CAN_MASK || env_of[tid] >= 0)) {
+  if (tid < n && OP != OP_READ_ENC) {
     const int env = env_of[tid];
     // (key / metrics / teacher action are read here, after the staging barrier: issuing the three loads next to the record
     // loads at kernel entry measured 1.6 % SLOWER on the whole pass, same-box A/B, round 2)
@@ -780,11 +500,10 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
     } else if (OP == OP_REPLAY) {
       env_reset(e, p, m, nullptr);
       e.elapsed = 0;
-      const int src = lvl ? lvl[row] : row;
-      const int L = a.lens[src];
+      const int L = a.lens[row];
       if (p.resample_n_clutter) e.sb(7) = (uint8_t)L;                       // adversarial.py:277-278
       for (int k = 0; k < L; ++k)
-        if (env_step_adversary(e, p, m, a.loc[(size_t)src * a.max_len + k], nullptr)) reset_agent(e);   // :280-283
+        if (env_step_adversary(e, p, m, a.loc[(size_t)row * a.max_len + k], nullptr)) reset_agent(e);   // :280-283
     } else if (OP == OP_MUTATE) {
       env_mutate_level(e, p, m, a.num_edits);
     }
@@ -798,10 +517,7 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
     }
   }
   __syncthreads();
-  if (OP != OP_READ_ENC) {
-    if (CAN_MASK) stage_out_masked<NT>(lds, a.rec, [&](int r) { return env_of[r]; }, n, tid);
-    else stage_out<NT>(lds, a.rec, [&](int r) { return env_of[r]; }, n, tid);
-  }
+  if (OP != OP_READ_ENC) stage_out<NT>(lds, a.rec, [&](int r) { return env_of[r]; }, n, tid);
   if (ADV_OUT) {
     if (OP != OP_READ_ENC && a.adv.random_z) {
       // generate_random_z (adversarial.py:449-450): (row, q) pairs, one Philox block = 4 floats each
@@ -821,51 +537,8 @@ __global__ void __launch_bounds__(Threads<EPB>::value) mg_level_kernel(const uin
     if (S == 15) emit_grid<15, NT>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
     else emit_grid<0, NT>(lds, lut, u8, f32, (size_t)row0, n, S, tid);
   } else {
-    if (CAN_MASK && lvl) render_emit_v_masked<EPB, NT>(lds, lut, a.stu, (size_t)row0, n, p, tid, env_of);
-    else render_emit_v<EPB, NT>(lds, lut, a.stu, (size_t)row0, n, p, tid);
+    render_emit_v<EPB, NT>(lds, lut, a.stu, (size_t)row0, n, p, tid);
   }
-}
-
-// ---- replay rollouts: the next queued level for every env that just finished an episode ---------------------------------
-// adversarial_runner.py:551-558 re-samples a level for each finished env, in env order, between two steps — on the host in
-// the reference.  The draws are ONE sequential stream (level_sampler.py:664-680) that the host has speculated ahead
-// (LevelSampler.prefetch_next_update); its next K entries sit in `q_rows` / `q_seeds`.  One workgroup walks the batch in env
-// order: the k-th finished env of this step takes entry cursor + k; level_idx[env] = table row to reset to (-1: not finished),
-// cur_seed[env] = its new level seed, solved[env] |= 1; cursor advances by the number of finished envs.  Past the end of the
-// queue envs get -1 and *overflow is set: the caller rolls the rollout back and runs it with host draws.
-constexpr int RPB = 1024;
-__global__ void __launch_bounds__(RPB) replay_pop_kernel(const uint8_t* __restrict__ ep_info, int B, const int32_t* __restrict__ q_rows,
-                                                         const int32_t* __restrict__ q_seeds, int K, int32_t* __restrict__ cursor,
-                                                         int32_t* __restrict__ overflow, int32_t* __restrict__ level_idx,
-                                                         int32_t* __restrict__ cur_seed, uint8_t* __restrict__ solved) {
-  __shared__ int wave_count[RPB / WAVE];
-  __shared__ int base;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) base = *cursor;
-  __syncthreads();
-  for (int e0 = 0; e0 < B; e0 += RPB) {
-    const int env = e0 + tid;
-    const bool fin = env < B && (ep_info[env] & DCD_INFO_EPISODE);
-    const unsigned long long bal = __ballot(fin);
-    if (lane == 0) wave_count[wave] = __popcll(bal);
-    __syncthreads();
-    int before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < RPB / WAVE; ++w) { const int c = wave_count[w]; before += (w < wave) ? c : 0; total += c; }
-    const int slot = base + before + __popcll(bal & ((1ull << lane) - 1ull));
-    if (env < B) {
-      int r = -1;
-      if (fin) {
-        if (slot < K) { r = q_rows[slot]; cur_seed[env] = q_seeds[slot]; if (solved) solved[env] = 1; }
-        else *overflow = 1;
-      }
-      level_idx[env] = r;
-    }
-    __syncthreads();
-    if (tid == 0) base += total;
-    __syncthreads();
-  }
-  if (tid == 0) *cursor = base;
 }
 
 __global__ void set_seed_kernel(uint8_t* rec, uint32_t* seed, const int64_t* seeds, int B) {
@@ -1193,31 +866,6 @@ int dcd_mg_reset_to_actions(DcdMg* h, const int64_t* actions, const int32_t* len
   LevelArgs a = base_args(h); a.loc = actions; a.lens = lens; a.max_len = max_len; a.idx = idx; a.n_rows = n; if (out) a.stu = *out;
   return launch_level<OP_REPLAY>(h, a, stream);
 }
-int dcd_mg_reset_to_encoding_rows(DcdMg* h, const uint8_t* table, const int32_t* level_idx, const DcdStudentObs* out, void* stream) {
-  CHECK_H(h);
-  NO_BIG(h, "dcd_mg_reset_to_encoding_rows");
-  if (!table || !level_idx) return dcd::fail("dcd_mg_reset_to_encoding_rows: null table / level_idx");
-  LevelArgs a = base_args(h); a.enc = table; a.level_idx = level_idx; a.idx = nullptr; a.n_rows = h->p.B; if (out) a.stu = *out;
-  return launch_level<OP_SET_ENCODING>(h, a, stream);
-}
-int dcd_mg_reset_to_actions_rows(DcdMg* h, const int64_t* table, const int32_t* table_lens, int32_t max_len, const int32_t* level_idx,
-                                 const DcdStudentObs* out, void* stream) {
-  CHECK_H(h);
-  NO_BIG(h, "dcd_mg_reset_to_actions_rows");
-  if (!table || !table_lens || !level_idx) return dcd::fail("dcd_mg_reset_to_actions_rows: null table / lens / level_idx");
-  LevelArgs a = base_args(h); a.loc = table; a.lens = table_lens; a.max_len = max_len; a.level_idx = level_idx; a.idx = nullptr; a.n_rows = h->p.B;
-  if (out) a.stu = *out;
-  return launch_level<OP_REPLAY>(h, a, stream);
-}
-int dcd_replay_pop(const uint8_t* ep_info, int32_t B, const int32_t* queue_rows, const int32_t* queue_seeds, int32_t K, int32_t* cursor,
-                   int32_t* overflow, int32_t* level_idx, int32_t* cur_seed, uint8_t* solved, void* stream) {
-  if (!ep_info || !queue_rows || !queue_seeds || !cursor || !overflow || !level_idx || !cur_seed || B <= 0 || K < 0)
-    return dcd::fail("dcd_replay_pop: NULL pointer or empty batch");
-  hipLaunchKernelGGL(replay_pop_kernel, dim3(1), dim3(RPB), 0, (hipStream_t)stream, ep_info, B, queue_rows, queue_seeds, K, cursor, overflow,
-                     level_idx, cur_seed, solved);
-  HIP_OK(hipGetLastError());
-  return 0;
-}
 int dcd_mg_mutate_level(DcdMg* h, int32_t num_edits, const DcdStudentObs* out, void* stream) {
   CHECK_H(h);
   NO_BIG(h, "dcd_mg_mutate_level");
@@ -1247,14 +895,7 @@ static int launch_step(DcdMg* h, int n_sets, const int64_t* actions0, const int6
   // raw-u8-only emission: no set wants an fp32 image
   auto u8_only = [&](const DcdStepOut& o) { return o.obs.image_u8 && !o.obs.image_f32 && !o.term_obs.image_f32; };
   const bool obs8 = u8_only(a.out[0]) && (n_sets == 1 || u8_only(a.out[1]));
-#define DCD_LAUNCH_LEAN(RR_, PAIR_) hipExtLaunchKernelGGL((mg_step_lean_kernel<RR_, PAIR_>), grid, dim3(Threads<64>::value), 0, (hipStream_t)stream, e0, e1, 0, (const uint8_t*)h->rec, (const uint32_t*)h->seed, actions0, h->p.B, actions1, h->p, a)
-  static const bool lean_ok = []() { const char* v = getenv("DCD_WIDE_LEAN"); return !(v && v[0] == '0'); }();
-  if (epb == 16) DCD_LAUNCH_EPB(16); else if (epb == 32) DCD_LAUNCH_EPB(32);
-  else if (obs8 && lean_ok) {                          // bandwidth regime, raw-u8 emission: the 4-wave workgroup (8 per CU)
-    if (n_sets == 2) { if (rr) DCD_LAUNCH_LEAN(true, true); else DCD_LAUNCH_LEAN(false, true); }
-    else { if (rr) DCD_LAUNCH_LEAN(true, false); else DCD_LAUNCH_LEAN(false, false); }
-  } else DCD_LAUNCH_EPB(64);
-#undef DCD_LAUNCH_LEAN
+  if (epb == 16) DCD_LAUNCH_EPB(16); else if (epb == 32) DCD_LAUNCH_EPB(32); else DCD_LAUNCH_EPB(64);
 #undef DCD_LAUNCH_EPB
 #undef DCD_LAUNCH_RR
 #undef DCD_LAUNCH_STEP
