@@ -601,7 +601,7 @@ def main():
         ps.eng.raise_errors()
         if not args.no_graph:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
+            with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):     # (a process group's watchdog thread may query events meanwhile)
                 ps.run()
 
         exchange = ScoreExchange(ps, world) if dist is not None else None

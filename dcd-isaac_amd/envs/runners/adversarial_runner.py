@@ -446,6 +446,12 @@ class AdversarialRunner:
     # 10k-node graphs"; the abort had nothing to do with graph size — see models/distributions.py::FixedCategorical.sample
     # and DESIGN.md §8.)
     GRAPH_CHUNK = 800
+    # Captures are thread-local: with a process group in the process, ProcessGroupNCCL's watchdog THREAD polls the events of
+    # finished collectives (hipEventQuery) at its own pace; under the default "global" capture mode such a call from any thread
+    # while this thread captures aborts the process ("operation not permitted when stream is capturing": the 1-rank RCCL test
+    # hit it once the updates between two captures got short enough, round 4).  Nothing another thread of this process does
+    # touches the capturing stream (the sampler's prefetch thread makes no HIP call).
+    GRAPH_CAPTURE_MODE = "thread_local"
 
     def _graphed(self, key, num_steps, fn):
         """fn(t0, t1) issues rollout steps [t0, t1).  First call: eager (warm-up); second: captured (one HIP graph per
@@ -462,7 +468,7 @@ class AdversarialRunner:
             state = []
             for t0 in range(0, num_steps, self.GRAPH_CHUNK):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=self.GRAPH_CAPTURE_MODE):
                     fn(t0, min(t0 + self.GRAPH_CHUNK, num_steps))
                 state.append(g)
             self._graphs[key] = state
@@ -609,7 +615,7 @@ class AdversarialRunner:
                     graphs = []
                     for t in range(num_steps):
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g):
+                        with torch.cuda.graph(g, capture_error_mode=self.GRAPH_CAPTURE_MODE):
                             dev_step(t)
                         graphs.append(g)
                     self._graphs[key] = graphs
