@@ -419,7 +419,10 @@ def sweep_large_b(device, obs="u8", sizes=(65536, 262144, 1048576), iters=30):
             eng.step(act, 0, out)
         n, ms = eng.profile_end()
         dt = ms / n * 1e-3
+        lean = B >= 32768 and obs == "u8" and os.environ.get("DCD_WIDE_LEAN", "1") != "0"
         res.append(dict(envs=B, us_per_launch=dt * 1e6, env_steps_per_s=B / dt,
+                        kernel=("mg_step_lean_kernel<false,false> (64 envs, 4 waves, 19.8 KB LDS per workgroup)" if lean else
+                                f"mg_step_kernel<false,{eng.step_epb(B)},false,false,{'true' if obs == 'u8' else 'false'}>"),
                         obs=obs, algorithmic_bytes_per_env_step=STEP_ALGO_BYTES[obs],
                         achieved_GBs=B * STEP_ALGO_BYTES[obs] / dt / 1e9, frac=B * STEP_ALGO_BYTES[obs] / dt / 1e9 / HBM_PEAK_GBS))
         eng.close()
