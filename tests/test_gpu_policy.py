@@ -293,7 +293,7 @@ def test_split_k_linear_matches_plain_linear():
     import torch.nn.functional as F
     from models.common import linear, matmul_tn
     torch.manual_seed(0)
-    for R, k, m in [(65536, 256, 32), (131072 + 4096, 27, 16), (70000, 32, 7)]:
+    for R, k, m in [(65536, 256, 32), (131072 + 4096, 27, 16), (70000, 32, 7), (65536 + 3, 64, 300), (110592, 32, 169)]:
         x = torch.randn(R, k, device=DEV, requires_grad=True)
         w = torch.randn(m, k, device=DEV, requires_grad=True)
         b = torch.randn(m, device=DEV, requires_grad=True)
