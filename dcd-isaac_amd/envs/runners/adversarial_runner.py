@@ -76,7 +76,7 @@ class AdversarialRunner:
         # DCD_REPLAY_QUEUE=1 (default; one process only): a replay rollout takes the levels of its finished episodes from a
         # device-resident queue of the sampler's speculated draws — ONE graph and one synchronisation per rollout instead of one
         # per step (_queued_replay_rollout); the stream is then speculated 8 draws per env ahead instead of 3
-        self.replay_queue = os.environ.get("DCD_REPLAY_QUEUE", "1") != "0"
+        self.replay_queue = os.environ.get("DCD_REPLAY_QUEUE", "1") != "0" and not self.distributed
         self.prefetch_stream_factor = int(os.environ.get("DCD_PREFETCH_STREAM", "8" if self.replay_queue else "3"))
         if process_group is not None:
             import torch.distributed as dist
@@ -596,7 +596,7 @@ class AdversarialRunner:
             fused.begin_rollout(num_steps)
         body = lambda t0, t1: self._student_rollout_body(agent, num_steps, t0, t1, level_replay, level_sampler, rollout_info)
         can_graph = self.use_hip_graphs and (fused is not None or self.graph_pytorch_nets)
-        if (host_resampling and can_graph and fused is not None and self.replay_queue and not self.distributed
+        if (host_resampling and can_graph and fused is not None and self.replay_queue
                 and self._queued_replay_rollout(agent, num_steps, level_sampler, rollout_info)):
             pass                                                        # the whole rollout ran as one graph on queued draws
         elif host_resampling and can_graph:
