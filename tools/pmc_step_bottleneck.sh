@@ -18,5 +18,5 @@ for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   rm -rf gpurun_out/prof/sq$i
   rocprofv3 --pmc $P --output-format csv -d gpurun_out/prof/sq$i -- python3 tools/sweep_only.py $SIZES > gpurun_out/prof_sq$i.out 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/prof_sq$i.out; }
 done
-python3 tools/pmc_reduce.py "mg_step_kernel" gpurun_out/prof/sq1 gpurun_out/prof/sq2 gpurun_out/prof/sq3 gpurun_out/prof/sq4 gpurun_out/prof/sq5 > gpurun_out/${TAG}_pmc_sq.json
+python3 tools/pmc_reduce.py "mg_step_" gpurun_out/prof/sq1 gpurun_out/prof/sq2 gpurun_out/prof/sq3 gpurun_out/prof/sq4 gpurun_out/prof/sq5 > gpurun_out/${TAG}_pmc_sq.json
 cat gpurun_out/${TAG}_pmc_sq.json
