@@ -371,6 +371,19 @@ def step_kernel_profile(ps, n=256):
 PASS_KERNELS = ("mg_step_kernel", "mg_level_kernel", "rollout_tail_kernel", "seg_score_lds_kernel", "seg_count (own launch)", "other (clone, regret)")
 
 
+def pass_kernel_algorithmic_bytes(ps):
+    """Algorithmic bytes per launch of the pass's kernels at this batch (SURVEY.md §8d per-unit figures x the units one launch
+    processes, both students per launch where the pass batches them)."""
+    B, T = ps.B, ps.T
+    n = 2 if ps.pair else 1
+    return {
+        "mg_step_kernel": (n * B * STEP_ALGO_BYTES[ps.obs], f"{STEP_ALGO_BYTES[ps.obs]} B per env-step x {n * B} env rows"),
+        "mg_level_kernel": (B * 705, f"705 B per teacher step (u8 full-grid observation) x {B} envs; 28 of the 30 launches per pass are teacher steps"),
+        "rollout_tail_kernel": (2 * T * B * (16 + 5 + 4), "per student and (t, env): GAE 16 B + return statistics 5 B + segment counts 4 B"),
+        "seg_score_lds_kernel": (2 * T * B * 24, "24 B per (t, env) per student (+ 32 B per episode record)"),
+    }
+
+
 def pass_kernel_times(ps, passes=8):
     """HIP-event begin -> end durations of EVERY kernel of the pass (dcd_profile_begin / dcd_profile_end: start / stop events
     attached to each dispatch by hipExtLaunchKernelGGL, no tracer attached), over `passes` eager passes of the benchmark
@@ -397,6 +410,10 @@ def pass_kernel_times(ps, passes=8):
             med = float(np.median(ms_np[tags_np == k]))
             out[name] = {"launches_per_pass": cnt[k] / passes, "avg_us": tot[k] / cnt[k] * 1e3, "median_us": med * 1e3, "max_us": mx[k] * 1e3,
                          "ms_per_pass": tot[k] / passes}
+            algo = pass_kernel_algorithmic_bytes(ps).get(name)
+            if algo is not None:                                   # HBM GB/s per kernel against the 8 TB/s peak (reporting)
+                out[name].update(algorithmic_bytes_per_launch=algo[0], achieved_GBs=algo[0] / (med * 1e-3) / 1e9,
+                                 frac_of_hbm_peak=algo[0] / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, bytes_basis=algo[1])
             total += tot[k] / passes
             total_med += med * cnt[k] / passes
     return {"how": "HIP start/stop events on each dispatch (hipExtLaunchKernelGGL), eager launches, no profiler attached",

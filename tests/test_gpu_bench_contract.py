@@ -30,6 +30,10 @@ def test_one_json_line_with_roofline_and_kernel_times():
     kt = d["kernel_times"]["kernels"]
     assert kt["mg_step_kernel"]["launches_per_pass"] == 256 and kt["mg_level_kernel"]["launches_per_pass"] == 30
     assert 0.9 < d["kernel_times"]["accounts_for"] < 1.15                 # the per-kernel event times account for the replayed pass
+    for name in ("mg_step_kernel", "mg_level_kernel", "rollout_tail_kernel", "seg_score_lds_kernel"):   # HBM GB/s per kernel
+        k = kt[name]
+        assert abs(k["achieved_GBs"] - k["algorithmic_bytes_per_launch"] / (k["median_us"] * 1e-6) / 1e9) < 1e-6 * k["achieved_GBs"]
+        assert 0 < k["frac_of_hbm_peak"] < 1
     assert d["grad_exchange"]["bytes"] > 9e7                               # the gradient all-reduce leg ran through RCCL
 
 
