@@ -36,3 +36,29 @@ cases = {
 for name, fn in cases.items():
     us = timeit(fn)
     print(f"{name:58s} {us:7.2f} us   {2 * N * H * G / us / 1e6:6.1f} TFLOP/s", flush=True)
+
+# the same products through the other BLAS backend torch can route to (default on this stack: see the first line printed)
+print("default preferred_blas_library:", torch.backends.cuda.preferred_blas_library())
+for lib in ("cublas", "cublaslt"):                 # (= rocBLAS, hipBLASLt on ROCm)
+    try:
+        torch.backends.cuda.preferred_blas_library(lib)
+    except Exception as e:                          # noqa: BLE001
+        print(lib, "not selectable:", e)
+        continue
+    print("---- preferred_blas_library =", torch.backends.cuda.preferred_blas_library())
+    for name in ("fwd addmm_(hm, w_hh.t() view)            [current]", "bwd mm(dg, w_hh, out)                    [current]",
+                 "bwd mm(dg, (w_hh_t contiguous).t() view, out)"):
+        us = timeit(cases[name])
+        print(f"{name:58s} {us:7.2f} us   {2 * N * H * G / us / 1e6:6.1f} TFLOP/s", flush=True)
+# the big contractions of a student update
+R = 1048576
+x1 = torch.randn(R, 152, device=dev); w1 = torch.randn(1024, 152, device=dev); gbig = torch.randn(R, 1024, device=dev)
+for lib in ("cublas", "cublaslt"):
+    try:
+        torch.backends.cuda.preferred_blas_library(lib)
+    except Exception:
+        continue
+    big = {"proj fwd  x1 @ w1.t()": lambda: x1 @ w1.t(), "proj dx   g @ w1": lambda: gbig @ w1}
+    for name, fn in big.items():
+        us = timeit(fn, n=20)
+        print(f"[{lib}] {name:40s} {us / 1e3:7.3f} ms   {2 * R * 152 * 1024 / us / 1e6:6.1f} TFLOP/s", flush=True)
