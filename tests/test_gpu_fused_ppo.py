@@ -131,3 +131,25 @@ def test_split_k_weight_gradient_with_a_row_count_no_power_of_two_divides(R):
     # ... and it is at least as close to the float64 product as the plain fp32 GEMM
     plain = a.t() @ b
     assert float((out.double() - ref).abs().max()) <= 2 * float((plain.double() - ref).abs().max()) + 1e-6 * scale
+
+
+def test_u8_minibatch_feeds_the_composed_path_through_its_lazy_fp32_view(monkeypatch):
+    """DCD_FUSED_PPO=0 on a u8 storage: the recurrent generator still hands over raw bytes (algos/storage.py::LazyU8Obs) and the
+    composed network asks for `image` / `direction` — materialised per minibatch by dcd_obs_u8_to_f32 — so the update equals the
+    reference's numbers exactly as the fp32 storage's does."""
+    from algos import ACAgent, PPO
+    from algos.storage import LazyU8Obs
+    from tests import ppo_fixtures as F
+    monkeypatch.setenv("DCD_FUSED_PPO", "0")
+    g = F.load("ppo.npz")
+    net = F.student_net(DEV)
+    st = F.student_storage(net, g, DEV, u8=True, wide=False)
+    adv = st.returns[:-1] - st.value_preds[:-1]
+    batch = next(st.recurrent_generator(adv, 1))
+    assert isinstance(batch[0], LazyU8Obs) and "image" not in batch[0]
+    assert torch.equal(batch[0]["image"].view(12, 4, 3, 5, 5), st.obs["image"][:-1]) or batch[0]["image"].shape == (48, 3, 5, 5)
+    algo = PPO(net, clip_param=0.2, ppo_epoch=2, num_mini_batch=1, value_loss_coef=0.5, entropy_coef=0.01, lr=1e-4, eps=1e-5,
+               max_grad_norm=0.5, clip_value_loss=True, log_grad_norm=True)
+    torch.manual_seed(2)
+    vl, al, ent, info = ACAgent(algo, st).update()
+    F.check_update(net, g, vl, al, ent, info, atol_w=2e-6)
