@@ -805,6 +805,6 @@ if __name__ == "__main__":
     import matplotlib.pyplot  # noqa: F401  (envs/box2d/bezier.py imports it at module level)
     install_shims()
     torch.set_num_threads(1)
-    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "entropy", "popart", "bezier", "f4_nets", "f4_adv", "staged", "f4_cr_adv"]     # name the sets to (re)generate
+    todo = sys.argv[1:] or ["scans", "sampler", "store", "ppo", "ppo_wide", "ppo_teacher", "entropy", "popart", "bezier", "f4_nets", "f4_adv", "staged", "f4_cr_adv"]     # name the sets to (re)generate
     for name in todo:
         globals()["gen_" + name]()
